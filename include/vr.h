@@ -1,0 +1,192 @@
+/*
+ * vr.h -- C ABI of libvr_hip.so: the MI355X (gfx950) implementation of the reference's
+ * isosurface ray-casting path.
+ *
+ * The reference (Zig) has no FFI layer; its boundary for this path is the ordinary call
+ *     raytrace.renderImage(src, forw, up, *img, viewport_width, *const SlimKDT, isoval, ...)
+ *         !struct { nodes_checked: u64 }                         (src/raytrace.zig:11-21)
+ * plus the objects it consumes: Data (src/Data.zig:4-6) and SlimKDT (src/SlimKDT.zig:15-19).
+ * Zig's packed Vec3 and zigimg.Image cannot cross a C ABI, so every entry point below takes plain
+ * pointers, sizes and scalars.  bindings/vr_hip.zig shows the `extern fn` declarations and the
+ * wrapper that keeps the renderImage signature.
+ *
+ * Conventions: every int-returning function returns VR_OK (0) or a negative error code
+ * (vr_strerror names it).  No exceptions, no global state besides contexts.  A context is bound to
+ * one device; calls on one context must be serialised by the caller (the reference renderer is
+ * single-threaded, src/main.zig:96-163).  Different contexts may be used from different threads.
+ */
+#ifndef VR_H
+#define VR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VR_OK 0
+#define VR_EARG (-1)      /* null pointer, zero size, out-of-range value                          */
+#define VR_ENOMEM (-2)    /* host allocation failed                                               */
+#define VR_ESTATE (-3)    /* call needs a volume / tree that has not been uploaded or built       */
+#define VR_ETOODEEP (-4)  /* tree heap index exceeds the slot limit: the reference's              */
+                          /* "FAILD TO BUILD KDT" case (src/main.zig:100-104)                     */
+#define VR_EIO (-5)       /* file could not be read                                               */
+#define VR_EFORMAT (-6)   /* malformed .vol file                                                  */
+#define VR_ENODEVICE (-7) /* no usable HIP device / the device is not gfx950                      */
+#define VR_EHIP_BASE (-1000) /* VR_EHIP_BASE - hipError_t                                         */
+
+/* Per-pixel flag stored in bits 24..31 of a cell/flag tap word. */
+#define VR_FLAG_MISS 0u /* ray entered the volume and left it without a hit (src/raytrace.zig:66-68) */
+#define VR_FLAG_HIT 1u  /* src/raytrace.zig:56-65                                                    */
+#define VR_FLAG_OOB 2u  /* ray never entered the root box (src/raytrace.zig:148-156, 53-55)          */
+
+/* Tree-partition heuristics, src/SlimKDT.zig:327-598 (ids are this library's). */
+enum vr_heuristic {
+    VR_H_ALWAYS_CENTER = 0,                 /* AlwaysCenterH              :359-367 */
+    VR_H_MINIMIZE_SPAN = 1,                 /* MinimizeSpanHeuristic      :327-357 */
+    VR_H_FLEXIBLE_FIRST5 = 2,               /* FlexibleFirst5             :369-375 */
+    VR_H_FLEXIBLE_FIRST10 = 3,              /* FlexibleFirst10            :377-383 */
+    VR_H_FLEXIBLE_AFTER10 = 4,              /* FlexibleAfter10            :385-391 */
+    VR_H_FLEXIBLE_AFTER15 = 5,              /* FlexibleAfter15            :392-398 */
+    VR_H_FLEXIBLE_AFTER20 = 6,              /* FlexibleAfter20            :400-406 */
+    VR_H_FLEXIBLE_CENTER_WEIGHTED5 = 7,     /* FlexibleCenterWeighted5    :408-438 */
+    VR_H_FLEXIBLE_CENTER_WEIGHTED10 = 8,    /* FlexibleCenterWeighted10   :440-470 */
+    VR_H_FLEXIBLE_CENTER_WEIGHTED30 = 9,    /* FlexibleCenterWeighted30   :472-502 */
+    VR_H_FLEXIBLE_CENTER_WEIGHTED50 = 10,   /* FlexibleCenterWeighted50   :504-534 */
+    VR_H_FLEXIBLE_CENTER_WEIGHTED75 = 11,   /* FlexibleCenterWeighted75   :536-566 */
+    VR_H_FLEXIBLE_CENTER_WEIGHTED100 = 12,  /* FlexibleCenterWeighted100  :568-598 */
+    VR_H_COUNT = 13
+};
+
+/* SlimKDT.PartitionBuildData, src/SlimKDT.zig:215-219. */
+typedef struct vr_build_stats {
+    uint64_t non_center_partition_count;
+    uint64_t layer_count;
+    uint64_t number_of_nodes;
+} vr_build_stats;
+
+/* Counters renderImage keeps (src/raytrace.zig:27-35); only nodes_checked is returned by the
+ * reference (:105), the rest are what its debug print shows (:79-104). One record per iso value. */
+typedef struct vr_render_stats {
+    uint64_t nodes_checked;      /* reference-defined count: one per traceRay loop iteration (:162) */
+    uint64_t hit_count;
+    uint64_t miss_count;
+    uint64_t oob_count;
+    uint64_t escape_help_events; /* :241 */
+    uint64_t moves;              /* MOVE steps (:199-246); not counted by the reference            */
+    uint64_t errors;             /* rays abandoned on a malformed tree (index or depth out of range); */
+                                 /* always 0 for trees the reference's builder can produce            */
+} vr_render_stats;
+
+/* Camera + image description: the scalar arguments of renderImage (src/raytrace.zig:12-18). */
+typedef struct vr_view {
+    float src[3];          /* ray origin                                  */
+    float forw[3];         /* view direction (the caller normalises it)   */
+    float up[3];           /* up vector, used as given (not normalised)   */
+    float viewport_width;  /* width of the image plane at distance 1      */
+    uint32_t width;        /* img.width                                   */
+    uint32_t height;       /* img.height                                  */
+} vr_view;
+
+/* Optional per-pixel parity taps, each `frames * rows * width` elements, any may be NULL.
+ * They expose RayRes (src/raytrace.zig:108-115) plus the hit cell, which the reference only holds
+ * transiently. */
+typedef struct vr_taps {
+    uint32_t *cell_flag; /* x | y<<8 | z<<16 | VR_FLAG_*<<24 ; cell is 0 unless the ray hit   */
+    float *t;            /* RayRes.t ; 0 for OOB rays                                          */
+    uint32_t *checked;   /* RayRes.checked_nodes                                               */
+    uint32_t *node;      /* heap index of the hit leaf ; 0 unless the ray hit                  */
+} vr_taps;
+
+typedef struct vr_ctx vr_ctx;
+
+const char *vr_strerror(int code);
+
+/* ---- host-side producers (no GPU needed) ------------------------------------------------ */
+
+/* Data.loadUCD (src/Data.zig:9-44): reads a .vol file.  *vox_out receives res[0]*res[1]*res[2]
+ * bytes, x slowest / z fastest (src/Data.zig:90-92); release with vr_free. */
+int vr_load_ucd(const char *path, uint8_t **vox_out, uint32_t res_out[3]);
+
+/* SlimKDT.newHeursiticPartition (src/SlimKDT.zig:222-322) on the host.  Produces the heap-indexed
+ * (children of i at 2i+1 / 2i+2, :24-30) array of 4-byte SlimNode words (:9-13: byte0 min, byte1
+ * max, byte2 partition, byte3 axis).  Slots no node occupies are 0.  max_slots = 0 means 2^32.
+ * Returns VR_ETOODEEP where the reference's realloc would fail.  Release *nodes_out with vr_free. */
+int vr_host_build_kdt(const uint8_t *vox, const uint32_t res[3], int heuristic, uint64_t max_slots,
+                      uint32_t **nodes_out, uint64_t *n_slots_out, uint8_t root_dim_out[3],
+                      vr_build_stats *stats_out);
+
+/* Camera of the reference driver (src/main.zig:31-43): forw = norm(f32(res/2) - pos),
+ * up = (forw x (0,1,0)) x forw (not normalised). */
+void vr_main_camera(const uint32_t res[3], const float pos[3], float forw_out[3], float up_out[3]);
+
+void vr_free(void *p);
+
+/* ---- device contexts -------------------------------------------------------------------- */
+
+/* One context per device.  Fails with VR_ENODEVICE when no HIP device is present or the device is
+ * not gfx950: there is no CPU fallback. */
+int vr_ctx_create(int device, vr_ctx **out);
+void vr_ctx_destroy(vr_ctx *ctx);
+
+/* Uploads Data.data verbatim (src/Data.zig:4-6, layout :90-92).  Needed by vr_build_kdt only:
+ * the render path never reads voxels (src/raytrace.zig:117-255 reads kdt.nodes alone). */
+int vr_upload_volume(vr_ctx *ctx, const uint8_t *vox, uint32_t rx, uint32_t ry, uint32_t rz);
+
+/* Uploads SlimKDT.nodes verbatim (src/SlimKDT.zig:17) with root_dim (:15).  Bits 26..31 of each
+ * word are ignored (undefined in the Zig packed struct). */
+int vr_upload_kdt(vr_ctx *ctx, const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3]);
+
+/* SlimKDT.newHeursiticPartition on the uploaded volume, result kept on the device.
+ * VR_H_ALWAYS_CENTER is built on the GPU; other heuristics are built by vr_host_build_kdt and
+ * uploaded. */
+int vr_build_kdt(vr_ctx *ctx, int heuristic, vr_build_stats *stats_out);
+
+/* Copies the device-resident tree back (for parity checks and caching). nodes_out may be NULL to
+ * query n_slots only. */
+int vr_download_kdt(vr_ctx *ctx, uint32_t *nodes_out, uint64_t cap_slots, uint64_t *n_slots_out,
+                    uint8_t root_dim_out[3]);
+
+/* ---- rendering -------------------------------------------------------------------------- */
+
+/* raytrace.renderImage (src/raytrace.zig:11-106) for one iso value into a HOST buffer of
+ * width*height*3 bytes (row-major, top row first, RGB8: img.pixels.rgb24).  stats_out and taps
+ * (host pointers) may be NULL.  Synchronous. */
+int vr_render(vr_ctx *ctx, const vr_view *view, uint8_t isoval, uint8_t *rgb24_out,
+              vr_render_stats *stats_out, const vr_taps *taps);
+
+/* The iso loop of the reference driver (src/main.zig:111-138): iso_count consecutive frames
+ * starting at iso_begin, frame k at rgb24_out + k*width*height*3; stats_out[k] per frame. Host
+ * buffers.  Synchronous. */
+int vr_render_sweep(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint32_t iso_count,
+                    uint8_t *rgb24_out, vr_render_stats *stats_out, const vr_taps *taps);
+
+/* Device-resident, asynchronous form used for sharded and timed runs: renders image rows
+ * [row_begin,row_end) of iso_count frames into DEVICE memory.  Frame k, row r (relative to
+ * row_begin) starts at d_rgb24 + ((k*(row_end-row_begin) + r) * width) * 3.  d_stats (device,
+ * iso_count records, may be NULL) is zeroed and filled on the stream.  d_taps members are device
+ * pointers.  `stream` is a hipStream_t (NULL = the context's own stream).  Returns after
+ * enqueueing. */
+int vr_render_device(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint32_t iso_count,
+                     uint32_t row_begin, uint32_t row_end, void *d_rgb24, void *d_stats,
+                     const vr_taps *d_taps, void *stream);
+
+/* Blocks until everything enqueued on the context's own stream has finished. */
+int vr_sync(vr_ctx *ctx);
+
+/* Kernel-time probe: while enabled, every vr_render_device call brackets its traversal kernel with
+ * a pair of HIP events on the launch stream.  vr_timing_read waits for the pairs recorded since the
+ * previous read, returns the sum of their elapsed times and their number, and forgets them. */
+int vr_set_timing(vr_ctx *ctx, int enabled);
+int vr_timing_read(vr_ctx *ctx, double *total_ms_out, uint32_t *launches_out);
+
+/* Traversal kernel selection: 0 = default (fastest verified), other values name the variants
+ * listed by vr_kernel_name.  All variants produce identical results. */
+int vr_set_kernel(vr_ctx *ctx, int variant);
+const char *vr_kernel_name(int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VR_H */

@@ -282,9 +282,10 @@ static vro_build_stats build_inner(build_ctx *c, box8 space, uint64_t idx, uint3
     int axis = box_largest_dim(space); /* :264 */
 
     if (idx >= c->cap) { /* :266-273 : the reference reallocs; a failed realloc fails the build */
+        if (idx >= c->max_slots) { c->err = VRO_ETOODEEP; return out; }
         uint64_t ncap = c->cap;
         while (idx >= ncap) ncap *= 2;
-        if (ncap > c->max_slots) { c->err = VRO_ETOODEEP; return out; }
+        if (ncap > c->max_slots) ncap = c->max_slots;
         uint32_t *nn = (uint32_t *)realloc(c->nodes, ncap * sizeof(uint32_t));
         if (!nn) { c->err = VRO_ENOMEM; return out; }
         memset(nn + c->cap, 0, (ncap - c->cap) * sizeof(uint32_t));

@@ -1,0 +1,66 @@
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DATA = os.path.join(ROOT, "tests", "data")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def c60_vox(oracle):
+    return oracle.load_ucd(os.path.join(DATA, "C60.vol"))
+
+
+@pytest.fixture(scope="session")
+def skull_vox():
+    raw = gzip.open(os.path.join(DATA, "Skull.vol.gz"), "rb").read()
+    return np.frombuffer(raw, dtype=np.uint8, count=68 * 256 * 256, offset=28).reshape(68, 256, 256).copy()
+
+
+@pytest.fixture(scope="session")
+def c60_tree(oracle, c60_vox):
+    nodes, rd, st = oracle.build_kdt(c60_vox)
+    return oracle.trim_nodes(nodes), rd, st
+
+
+@pytest.fixture(scope="session")
+def skull_tree(oracle, skull_vox):
+    nodes, rd, st = oracle.build_kdt(skull_vox)
+    return oracle.trim_nodes(nodes), rd, st
+
+
+@pytest.fixture(scope="session")
+def golden_gray():
+    return np.load(os.path.join(GOLDEN, "c60_renders_512.npz"))["gray"]
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """Host build of the lane code (tests/emu): the same header the GPU kernels compile."""
+    import ctypes as C
+    src = os.path.join(ROOT, "tests", "emu", "vr_emu.cpp")
+    out = os.path.join(ROOT, "tests", "emu", "libvr_emu.so")
+    hdr = os.path.join(ROOT, "volumerenderer_amd", "csrc", "vr_trace_core.h")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared",
+                               "-o", out, src])
+    return C.CDLL(out)

@@ -1,0 +1,69 @@
+/*
+ * vr_emu.cpp -- TEST HARNESS: runs the lane code of volumerenderer_amd/csrc/vr_trace_core.h on the
+ * CPU, one pixel at a time, so the traversal variants can be checked against the oracle without a
+ * GPU.  Not part of the product library and never loaded by it.
+ */
+#include <cstdint>
+#include <cstring>
+
+#include "../../volumerenderer_amd/csrc/vr_trace_core.h"
+
+namespace {
+struct HostFetch {
+    const uint32_t *nodes;
+    uint32_t operator()(uint32_t i) const { return nodes[i]; }
+};
+struct HostStack {
+    uint16_t rec[VR_MAX_DEPTH + 1];
+    void push(uint32_t level, uint32_t r) { rec[level] = (uint16_t)r; }
+    uint32_t pop(uint32_t level) const { return rec[level]; }
+};
+} // namespace
+
+extern "C" int vr_emu_render(int variant, const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3],
+                             const float src[3], const float forw[3], const float up[3], uint32_t width,
+                             uint32_t height, float viewport_width, uint32_t iso, uint8_t *rgb, uint32_t *cell_flag,
+                             float *t_out, uint32_t *checked, uint32_t *node, uint64_t *sums /*7*/)
+{
+    VrViewK k;
+    k.ox = src[0]; k.oy = src[1]; k.oz = src[2];
+    k.fx = forw[0]; k.fy = forw[1]; k.fz = forw[2];
+    k.ux = up[0]; k.uy = up[1]; k.uz = up[2];
+    k.rx = k.fy * k.uz - k.fz * k.uy;
+    k.ry = k.fz * k.ux - k.fx * k.uz;
+    k.rz = k.fx * k.uy - k.fy * k.ux;
+    k.pixel_size = viewport_width / (float)width;
+    k.half_w = (float)(width / 2);
+    k.half_h = (float)(height / 2);
+    k.width = width; k.height = height;
+    k.rdx = root_dim[0]; k.rdy = root_dim[1]; k.rdz = root_dim[2];
+    k.root_hi = vr_pack10(k.rdx, k.rdy, k.rdz);
+    k.n_slots = n_slots;
+    std::memset(sums, 0, 7 * sizeof(uint64_t));
+    for (uint32_t yi = 0; yi < height; yi++)
+        for (uint32_t xi = 0; xi < width; xi++) {
+            VrRay ray = vr_make_ray(k, xi, yi);
+            VrHit h;
+            if (variant == 1) {
+                h = vr_trace_restart(k, ray, iso, HostFetch{ nodes });
+            } else {
+                HostStack st;
+                h = vr_trace_resume(k, ray, iso, HostFetch{ nodes }, st);
+            }
+            uint64_t pix = (uint64_t)yi * width + xi;
+            uint8_t g = h.flag == 1u ? vr_shade(h.t) : 0;
+            rgb[pix * 3] = rgb[pix * 3 + 1] = rgb[pix * 3 + 2] = g;
+            cell_flag[pix] = h.cell | (h.flag << 24);
+            t_out[pix] = h.flag == 2u ? 0.0f : h.t;
+            checked[pix] = h.checked;
+            node[pix] = h.node;
+            sums[0] += h.checked;
+            sums[1] += h.flag == 1u;
+            sums[2] += h.flag == 0u;
+            sums[3] += h.flag == 2u;
+            sums[4] += h.escapes;
+            sums[5] += h.moves;
+            sums[6] += h.error;
+        }
+    return 0;
+}

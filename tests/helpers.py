@@ -1,0 +1,45 @@
+import ctypes as C
+
+import numpy as np
+
+
+def emu_render(L, variant, nodes, rd, pos, f, u, w, h, vp, iso):
+    """Runs the kernels' lane code on the CPU (tests/emu/vr_emu.cpp)."""
+    rgb = np.zeros((h, w, 3), np.uint8)
+    cf = np.zeros((h, w), np.uint32)
+    tt = np.zeros((h, w), np.float32)
+    ck = np.zeros((h, w), np.uint32)
+    nd = np.zeros((h, w), np.uint32)
+    sums = np.zeros(7, np.uint64)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+    L.vr_emu_render(int(variant), C.c_void_p(nodes.ctypes.data), C.c_uint64(len(nodes)),
+                    (C.c_uint8 * 3)(*[int(x) for x in rd]), f3(pos), f3(f), f3(u), C.c_uint32(w), C.c_uint32(h),
+                    C.c_float(vp), C.c_uint32(iso), C.c_void_p(rgb.ctypes.data), C.c_void_p(cf.ctypes.data),
+                    C.c_void_p(tt.ctypes.data), C.c_void_p(ck.ctypes.data), C.c_void_p(nd.ctypes.data),
+                    C.c_void_p(sums.ctypes.data))
+    return {"rgb": rgb, "cell_flag": cf, "t": tt, "checked": ck, "node": nd, "sums": sums}
+
+
+def assert_same_render(got, ref, what=""):
+    """Bit-exact comparison of every per-pixel output against the oracle."""
+    assert (got["rgb"] == ref["rgb"]).all(), "%s: pixels differ (%d)" % (what, int((got["rgb"] != ref["rgb"]).sum()))
+    assert (got["cell_flag"] == ref["cell_flag"]).all(), "%s: hit cells / flags differ" % what
+    assert (got["t"].view(np.uint32) == ref["t"].view(np.uint32)).all(), "%s: t bit patterns differ" % what
+    assert (got["checked"] == ref["checked"]).all(), "%s: checked_nodes differ" % what
+    assert (got["node"] == ref["node"]).all(), "%s: hit leaf indices differ" % what
+
+
+def random_volume(rng, shape, kind):
+    if kind == "noise":
+        return rng.integers(0, 256, size=shape, dtype=np.uint8)
+    if kind == "smooth":
+        g = np.stack(np.meshgrid(*[np.linspace(-1, 1, s) for s in shape], indexing="ij"))
+        r = np.sqrt((g ** 2).sum(0))
+        return np.clip(255 * np.exp(-3 * r * r) + rng.normal(0, 6, shape), 0, 255).astype(np.uint8)
+    if kind == "sparse":
+        v = np.zeros(shape, np.uint8)
+        m = rng.random(shape) < 0.03
+        v[m] = rng.integers(1, 256, size=int(m.sum()), dtype=np.uint8)
+        return v
+    raise ValueError(kind)

@@ -1,0 +1,242 @@
+"""GPU parity: libvr_hip.so through its C ABI against the CPU oracle and the reference's committed renders.
+
+Bar: bit-exact on every per-ray output -- RGB bytes, hit cell index, flag, t bit pattern, hit leaf index and
+the reference-defined checked_nodes count -- for every traversal kernel variant."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import volumerenderer_amd as vr
+from volumerenderer_amd import capi
+from helpers import assert_same_render, random_volume
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [capi.KERNEL_RESTART_GLOBAL, capi.KERNEL_RESTART_LDS, capi.KERNEL_RESUME]
+
+
+@pytest.fixture(scope="module")
+def c60_renderer(c60_tree):
+    nodes, rd, _ = c60_tree
+    r = vr.Renderer(0)
+    r.upload_kdt(vr.SlimKDT(nodes, rd))
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def skull_renderer(skull_tree):
+    nodes, rd, _ = skull_tree
+    r = vr.Renderer(0)
+    r.upload_kdt(vr.SlimKDT(nodes, rd))
+    yield r
+    r.close()
+
+
+def _gpu(renderer, pos, forw, up, w, h, vp, iso):
+    img = vr.Image(w, h)
+    res = renderer.renderImage(pos, forw, up, img, vp, iso, taps=True)
+    res["rgb"] = img.pixels
+    return res
+
+
+def _check_stats(res, ref):
+    st, o = res["stats"], ref["stats"]
+    assert st["nodes_checked"] == o.nodes_checked
+    assert st["hit_count"] == o.hit_count and st["miss_count"] == o.miss_count and st["oob_count"] == o.oob_count
+    assert st["escape_help_events"] == o.escape_help_events and st["moves"] == o.moves
+    assert st["errors"] == 0
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_c60_512_matches_oracle(oracle, c60_vox, c60_tree, c60_renderer, variant):
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    c60_renderer.set_kernel(variant)
+    for iso in (0, 1, 100, 255):
+        ref = oracle.render(nodes, rd, pos, forw, up, 512, 512, 2.0, iso)
+        got = _gpu(c60_renderer, pos, forw, up, 512, 512, 2.0, iso)
+        assert_same_render(got, ref, "C60 512 iso %d variant %d" % (iso, variant))
+        _check_stats(got, ref)
+    c60_renderer.set_kernel(capi.KERNEL_DEFAULT)
+
+
+def test_c60_sweep_matches_all_256_reference_renders(oracle, c60_vox, c60_renderer, golden_gray):
+    """The reference's own artefacts: renders/out_iso{0..255}.png, as one vr_render_sweep call."""
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    out = c60_renderer.renderSweep(pos, forw, up, 512, 512, 2.0, 0, 256)
+    rgb = out["rgb"]
+    assert (rgb[..., 0] == golden_gray).all(), "%d pixels differ" % int((rgb[..., 0] != golden_gray).sum())
+    assert (rgb[..., 0] == rgb[..., 1]).all() and (rgb[..., 1] == rgb[..., 2]).all()
+    assert all(s["oob_count"] == 216422 and s["errors"] == 0 for s in out["stats"])
+
+
+def test_c60_1024_matches_oracle(oracle, c60_vox, c60_tree, c60_renderer):
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    ref = oracle.render(nodes, rd, pos, forw, up, 1024, 1024, 2.0, 100)
+    got = _gpu(c60_renderer, pos, forw, up, 1024, 1024, 2.0, 100)
+    assert_same_render(got, ref, "C60 1024 iso 100")
+    _check_stats(got, ref)
+    assert ref["stats"].nodes_checked == 13759010  # the value the survey measured for this configuration
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_skull_matches_oracle(oracle, skull_vox, skull_tree, skull_renderer, variant):
+    nodes, rd, _ = skull_tree
+    pos, forw, up = oracle.main_camera(skull_vox.shape)
+    skull_renderer.set_kernel(variant)
+    for iso in (0, 80, 255):
+        ref = oracle.render(nodes, rd, pos, forw, up, 384, 384, 2.0, iso)
+        got = _gpu(skull_renderer, pos, forw, up, 384, 384, 2.0, iso)
+        assert_same_render(got, ref, "Skull 384 iso %d variant %d" % (iso, variant))
+        _check_stats(got, ref)
+    skull_renderer.set_kernel(capi.KERNEL_DEFAULT)
+
+
+def test_skull_1024_iso80_matches_oracle(oracle, skull_vox, skull_tree, skull_renderer):
+    nodes, rd, _ = skull_tree
+    pos, forw, up = oracle.main_camera(skull_vox.shape)
+    ref = oracle.render(nodes, rd, pos, forw, up, 1024, 1024, 2.0, 80)
+    got = _gpu(skull_renderer, pos, forw, up, 1024, 1024, 2.0, 80)
+    assert_same_render(got, ref, "Skull 1024 iso 80")
+    _check_stats(got, ref)
+    assert ref["stats"].nodes_checked == 35470121
+
+
+def test_skull_sweep_properties_at_full_size(oracle, skull_vox, skull_renderer):
+    """Full-size (1024^2) sweep checked through properties that need no oracle run: the OOB mask is the
+    same for every iso, hit + miss + oob = pixels, gray levels stay in the shading range, every kernel
+    variant agrees, and a sweep equals single renders."""
+    pos, forw, up = oracle.main_camera(skull_vox.shape)
+    isos = 8
+    out = skull_renderer.renderSweep(pos, forw, up, 1024, 1024, 2.0, 76, isos, taps=True)
+    flags = out["cell_flag"] >> 24
+    oob = flags[0] == capi.FLAG_OOB
+    for k in range(isos):
+        assert ((flags[k] == capi.FLAG_OOB) == oob).all()
+        st = out["stats"][k]
+        assert st["hit_count"] + st["miss_count"] + st["oob_count"] == 1024 * 1024
+        assert st["hit_count"] == int((flags[k] == capi.FLAG_HIT).sum())
+        assert st["nodes_checked"] == int(out["checked"][k].astype(np.uint64).sum())
+        g = out["rgb"][k, ..., 0]
+        assert ((g == 0) | (g >= 55)).all() and (g[flags[k] != capi.FLAG_HIT] == 0).all()
+    single = _gpu(skull_renderer, pos, forw, up, 1024, 1024, 2.0, 80)
+    assert (single["rgb"] == out["rgb"][4]).all() and (single["checked"] == out["checked"][4]).all()
+    for variant in (capi.KERNEL_RESTART_LDS,):
+        skull_renderer.set_kernel(variant)
+        other = _gpu(skull_renderer, pos, forw, up, 1024, 1024, 2.0, 80)
+        skull_renderer.set_kernel(capi.KERNEL_DEFAULT)
+        for key in ("rgb", "cell_flag", "checked", "node"):
+            assert (other[key] == single[key]).all()
+        assert (other["t"].view(np.uint32) == single["t"].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("heuristic", ["FlexibleFirst5", "FlexibleCenterWeighted30", "FlexibleCenterWeighted75"])
+def test_heuristic_trees(oracle, c60_vox, heuristic):
+    k = vr.SlimKDT.newHeursiticPartition(vr.Data(c60_vox), heuristic)
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    with vr.Renderer(0) as r:
+        r.upload_kdt(k)
+        for iso in (30, 128, 222):
+            ref = oracle.render(k.nodes, k.root_dim, pos, forw, up, 256, 256, 2.0, iso)
+            got = _gpu(r, pos, forw, up, 256, 256, 2.0, iso)
+            assert_same_render(got, ref, "%s iso %d" % (heuristic, iso))
+            _check_stats(got, ref)
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (37, 53), (130, 17), (256, 1)])
+def test_ragged_image_sizes(oracle, c60_vox, c60_tree, c60_renderer, size):
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    w, h = size
+    for variant in VARIANTS:
+        c60_renderer.set_kernel(variant)
+        ref = oracle.render(nodes, rd, pos, forw, up, w, h, 0.4, 100)
+        got = _gpu(c60_renderer, pos, forw, up, w, h, 0.4, 100)
+        assert_same_render(got, ref, "size %s variant %d" % (size, variant))
+        _check_stats(got, ref)
+    c60_renderer.set_kernel(capi.KERNEL_DEFAULT)
+
+
+def test_small_volumes_and_odd_cameras(oracle):
+    rng = np.random.default_rng(11)
+    for shape, kind in [((2, 2, 2), "noise"), ((5, 9, 3), "noise"), ((33, 20, 41), "smooth"), ((40, 40, 40), "sparse")]:
+        vox = random_volume(rng, shape, kind)
+        k = vr.SlimKDT.newHeursiticPartition(vr.Data(vox), "AlwaysCenter")
+        with vr.Renderer(0) as r:
+            r.upload_kdt(k)
+            for cam in [(-30.0, -300.0, -30.0), (350.0, 20.0, 10.0), (8.0, 8.0, -320.0), (-200.0, 260.0, 190.0)]:
+                pos, forw, up = oracle.main_camera(shape, cam)
+                for iso in (0, 40, 200):
+                    ref = oracle.render(k.nodes, k.root_dim, pos, forw, up, 96, 64, 0.5, iso)
+                    got = _gpu(r, pos, forw, up, 96, 64, 0.5, iso)
+                    assert_same_render(got, ref, "%s %s iso %d" % (shape, cam, iso))
+                    _check_stats(got, ref)
+
+
+def test_axis_parallel_rays_are_oob(oracle):
+    vox = np.full((8, 8, 8), 200, np.uint8)
+    k = vr.SlimKDT.newHeursiticPartition(vr.Data(vox))
+    pos = np.array([3.5, -300.0, 3.5], np.float32)
+    forw = np.array([0.0, 1.0, 0.0], np.float32)
+    up = np.array([0.0, 0.0, 1.0], np.float32)
+    ref = oracle.render(k.nodes, k.root_dim, pos, forw, up, 9, 9, 0.02, 100)
+    with vr.Renderer(0) as r:
+        r.upload_kdt(k)
+        got = _gpu(r, pos, forw, up, 9, 9, 0.02, 100)
+    assert_same_render(got, ref, "axis-parallel")
+    assert (got["cell_flag"][4, 4] >> 24) == capi.FLAG_OOB
+
+
+def test_device_entry_point_rows_and_isos(oracle, c60_vox, c60_tree, c60_renderer):
+    """vr_render_device: row ranges and iso ranges into device memory (the sharded form), assembled on the
+    host, equal the full sweep."""
+    import torch
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    W, H = 200, 120
+    full = c60_renderer.renderSweep(pos, forw, up, W, H, 2.0, 98, 4)
+    L = capi.lib()
+    v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+    pieces = []
+    checked = 0
+    for r0, r1 in [(0, 50), (50, 51), (51, 120)]:
+        rows = r1 - r0
+        d_rgb = torch.zeros((4, rows, W, 3), dtype=torch.uint8, device="cuda")
+        d_stats = torch.zeros((4, 7), dtype=torch.int64, device="cuda")
+        capi.check(L.vr_render_device(c60_renderer.handle, C.byref(v), 98, 4, r0, r1, d_rgb.data_ptr(),
+                                      d_stats.data_ptr(), None, None), "vr_render_device")
+        capi.check(L.vr_sync(c60_renderer.handle), "vr_sync")
+        pieces.append(d_rgb.cpu().numpy())
+        checked += int(d_stats[:, 0].sum())
+    assert (np.concatenate(pieces, axis=1) == full["rgb"]).all()
+    assert checked == sum(s["nodes_checked"] for s in full["stats"])
+
+
+def test_error_paths_on_device(c60_tree):
+    nodes, rd, _ = c60_tree
+    L = capi.lib()
+    with vr.Renderer(0) as r:
+        v = vr.raytrace._view((0, 0, 0), (0, 1, 0), (0, 0, 1), 8, 8, 2.0)
+        buf = np.zeros(8 * 8 * 3, np.uint8)
+        assert L.vr_render(r.handle, C.byref(v), 0, buf.ctypes.data, None, None) == capi.VR_ESTATE
+        assert L.vr_build_kdt(r.handle, 0, None) == capi.VR_ESTATE
+        r.upload_kdt(vr.SlimKDT(nodes, rd))
+        assert L.vr_render(r.handle, C.byref(v), 0, None, None, None) == capi.VR_EARG
+        assert L.vr_render_sweep(r.handle, C.byref(v), 200, 100, buf.ctypes.data, None, None) == capi.VR_EARG
+        v.width = 0
+        assert L.vr_render(r.handle, C.byref(v), 0, buf.ctypes.data, None, None) == capi.VR_EARG
+        assert L.vr_set_kernel(r.handle, 77) == capi.VR_EARG
+        assert L.vr_upload_kdt(r.handle, nodes.ctypes.data, 0, (C.c_uint8 * 3)(1, 1, 1)) == capi.VR_EARG
+
+
+def test_build_on_context_and_download(oracle, c60_vox, c60_tree):
+    nodes, rd, st = c60_tree
+    with vr.Renderer(0) as r:
+        r.upload_volume(vr.Data(c60_vox))
+        bs = r.build_kdt("AlwaysCenter")
+        assert bs.number_of_nodes == st.number_of_nodes and bs.layer_count == st.layer_count
+        got, grd = r.download_kdt()
+        assert (grd == rd).all() and len(got) == len(nodes) and (got == nodes).all()

@@ -1,0 +1,70 @@
+"""The kernels' lane code (vr_trace_core.h), compiled for the host, against the oracle.  This checks
+the algorithmic claim of the resume traversal -- same hit, same t bits, same reference-defined
+checked count as the root-restart loop -- before anything runs on a GPU."""
+import numpy as np
+import pytest
+
+from helpers import assert_same_render, emu_render, random_volume
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("iso", [0, 1, 57, 100, 200, 255])
+def test_c60_lane_code(oracle, emu_lib, c60_vox, c60_tree, variant, iso):
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    ref = oracle.render(nodes, rd, pos, forw, up, 160, 160, 2.0, iso)
+    got = emu_render(emu_lib, variant, nodes, rd, pos, forw, up, 160, 160, 2.0, iso)
+    assert_same_render(got, ref, "C60 iso %d variant %d" % (iso, variant))
+    assert int(got["sums"][0]) == ref["stats"].nodes_checked
+    assert int(got["sums"][6]) == 0
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_skull_lane_code(oracle, emu_lib, skull_vox, skull_tree, variant):
+    nodes, rd, _ = skull_tree
+    pos, forw, up = oracle.main_camera(skull_vox.shape)
+    for iso in (0, 80, 255):
+        ref = oracle.render(nodes, rd, pos, forw, up, 128, 128, 2.0, iso)
+        got = emu_render(emu_lib, variant, nodes, rd, pos, forw, up, 128, 128, 2.0, iso)
+        assert_same_render(got, ref, "Skull iso %d variant %d" % (iso, variant))
+
+
+@pytest.mark.parametrize("heuristic", ["FlexibleFirst5", "FlexibleCenterWeighted30"])
+def test_heuristic_trees_lane_code(oracle, emu_lib, c60_vox, heuristic):
+    nodes, rd, _ = oracle.build_kdt(c60_vox, heuristic)
+    nodes = oracle.trim_nodes(nodes)
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    for iso in (30, 128):
+        ref = oracle.render(nodes, rd, pos, forw, up, 96, 96, 2.0, iso)
+        got = emu_render(emu_lib, 3, nodes, rd, pos, forw, up, 96, 96, 2.0, iso)
+        assert_same_render(got, ref, "%s iso %d" % (heuristic, iso))
+
+
+def test_odd_cameras_and_small_volumes(oracle, emu_lib):
+    rng = np.random.default_rng(7)
+    for shape, kind in [((5, 9, 3), "noise"), ((33, 20, 41), "smooth"), ((16, 16, 16), "sparse"), ((2, 2, 2), "noise")]:
+        vox = random_volume(rng, shape, kind)
+        nodes, rd, _ = oracle.build_kdt(vox)
+        nodes = oracle.trim_nodes(nodes)
+        cams = [(-30.0, -300.0, -30.0), (350.0, 20.0, 10.0), (8.0, 8.0, -320.0), (-200.0, 260.0, 190.0)]
+        for pos in cams:
+            pos, forw, up = oracle.main_camera(shape, pos)
+            for iso in (0, 40, 200):
+                ref = oracle.render(nodes, rd, pos, forw, up, 64, 48, 0.5, iso)
+                for variant in (1, 3):
+                    got = emu_render(emu_lib, variant, nodes, rd, pos, forw, up, 64, 48, 0.5, iso)
+                    assert_same_render(got, ref, "%s %s iso %d v%d" % (shape, pos, iso, variant))
+
+
+def test_axis_parallel_rays_are_oob(oracle, emu_lib):
+    # |d_a| < 1e-8 makes the entry plane hit +inf, so the ray is reported out of bounds (src/geo.zig:417)
+    vox = np.full((8, 8, 8), 200, np.uint8)
+    nodes, rd, _ = oracle.build_kdt(vox)
+    nodes = oracle.trim_nodes(nodes)
+    pos = np.array([3.5, -300.0, 3.5], np.float32)
+    forw = np.array([0.0, 1.0, 0.0], np.float32)
+    up = np.array([0.0, 0.0, 1.0], np.float32)
+    ref = oracle.render(nodes, rd, pos, forw, up, 9, 9, 0.02, 100)
+    got = emu_render(emu_lib, 3, nodes, rd, pos, forw, up, 9, 9, 0.02, 100)
+    assert_same_render(got, ref, "axis-parallel")
+    assert (ref["cell_flag"][4, 4] >> 24) == 2  # the centre ray is exactly axis-parallel

@@ -1,0 +1,319 @@
+/*
+ * vr_capi.hip -- the extern "C" boundary of libvr_hip.so (declared in include/vr.h): device
+ * contexts, uploads of the volume and the SlimKDT node array, and the render entry points that
+ * stand in for raytrace.renderImage (src/raytrace.zig:11-106) and the iso loop of the reference
+ * driver (src/main.zig:111-138).
+ */
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "vr_internal.h"
+
+#define VR_HIP(call)                                           \
+    do {                                                       \
+        hipError_t e__ = (call);                               \
+        if (e__ != hipSuccess) return VR_EHIP_BASE - (int)e__; \
+    } while (0)
+
+struct vr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    /* volume (only the tree builder reads it) */
+    uint8_t *d_vox = nullptr;
+    uint32_t res[3] = { 0, 0, 0 };
+    uint8_t *h_vox = nullptr; /* host copy for the host-side builder */
+    /* tree */
+    uint32_t *d_nodes = nullptr;
+    uint64_t n_slots = 0;
+    uint8_t root_dim[3] = { 0, 0, 0 };
+    /* staging for the host-buffer entry points, grown on demand */
+    uint8_t *d_rgb = nullptr;
+    size_t rgb_cap = 0;
+    vr_render_stats *d_stats = nullptr;
+    size_t stats_cap = 0;
+    void *d_tap[4] = { nullptr, nullptr, nullptr, nullptr };
+    size_t tap_cap[4] = { 0, 0, 0, 0 };
+    /* options */
+    int variant = VR_KERNEL_DEFAULT;
+    int timing = 0;
+    std::vector<hipEvent_t> ev; /* start/stop pairs of the timed launches not yet read back */
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int ensure(void **p, size_t *cap, size_t need)
+{
+    if (*cap >= need) return VR_OK;
+    if (*p) { VR_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
+    VR_HIP(hipMalloc(p, need));
+    *cap = need;
+    return VR_OK;
+}
+
+/* the per-image constants of renderImage, src/raytrace.zig:22-24,38; computed in strict f32 */
+VrViewK make_view(const vr_ctx *ctx, const vr_view *view)
+{
+    VrViewK k;
+    k.ox = view->src[0]; k.oy = view->src[1]; k.oz = view->src[2];
+    k.fx = view->forw[0]; k.fy = view->forw[1]; k.fz = view->forw[2];
+    k.ux = view->up[0]; k.uy = view->up[1]; k.uz = view->up[2];
+    /* right = forw.cross(up), src/geo.zig:115-121 */
+    k.rx = k.fy * k.uz - k.fz * k.uy;
+    k.ry = k.fz * k.ux - k.fx * k.uz;
+    k.rz = k.fx * k.uy - k.fy * k.ux;
+    k.pixel_size = view->viewport_width / (float)view->width;
+    k.half_w = (float)(view->width / 2);
+    k.half_h = (float)(view->height / 2);
+    k.width = view->width;
+    k.height = view->height;
+    k.rdx = ctx->root_dim[0]; k.rdy = ctx->root_dim[1]; k.rdz = ctx->root_dim[2];
+    k.root_hi = vr_pack10(k.rdx, k.rdy, k.rdz);
+    k.n_slots = ctx->n_slots;
+    return k;
+}
+
+int check_view(const vr_view *view)
+{
+    if (!view || view->width == 0 || view->height == 0) return VR_EARG;
+    if ((uint64_t)view->width * view->height > ((uint64_t)1 << 31)) return VR_EARG;
+    return VR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int vr_ctx_create(int device, vr_ctx **out)
+{
+    if (!out) return VR_EARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VR_ENODEVICE;
+    if (device < 0 || device >= n) return VR_EARG;
+    hipDeviceProp_t prop;
+    VR_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VR_ENODEVICE;
+    vr_ctx *c = new (std::nothrow) vr_ctx();
+    if (!c) return VR_ENOMEM;
+    c->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        vr_ctx_destroy(c);
+        return VR_EHIP_BASE - (int)e;
+    }
+    *out = c;
+    return VR_OK;
+}
+
+void vr_ctx_destroy(vr_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_vox) (void)hipFree(c->d_vox);
+    if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_rgb) (void)hipFree(c->d_rgb);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    for (int i = 0; i < 4; i++)
+        if (c->d_tap[i]) (void)hipFree(c->d_tap[i]);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    std::free(c->h_vox);
+    delete c;
+}
+
+int vr_upload_volume(vr_ctx *c, const uint8_t *vox, uint32_t rx, uint32_t ry, uint32_t rz)
+{
+    if (!c || !vox || rx < 2 || ry < 2 || rz < 2 || rx > 256 || ry > 256 || rz > 256) return VR_EARG;
+    VR_HIP(hipSetDevice(c->device));
+    const size_t n = (size_t)rx * ry * rz;
+    if (c->d_vox) { VR_HIP(hipFree(c->d_vox)); c->d_vox = nullptr; }
+    std::free(c->h_vox);
+    c->h_vox = (uint8_t *)std::malloc(n);
+    if (!c->h_vox) return VR_ENOMEM;
+    std::memcpy(c->h_vox, vox, n);
+    VR_HIP(hipMalloc((void **)&c->d_vox, n));
+    VR_HIP(hipMemcpy(c->d_vox, vox, n, hipMemcpyHostToDevice));
+    c->res[0] = rx; c->res[1] = ry; c->res[2] = rz;
+    return VR_OK;
+}
+
+int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3])
+{
+    if (!c || !nodes || !n_slots || !root_dim) return VR_EARG;
+    if (n_slots > ((uint64_t)1 << 32)) return VR_EARG; /* heap indices are u32, src/SlimKDT.zig:24-34 */
+    if (root_dim[0] == 0 || root_dim[1] == 0 || root_dim[2] == 0) return VR_EARG;
+    VR_HIP(hipSetDevice(c->device));
+    if (c->d_nodes) { VR_HIP(hipFree(c->d_nodes)); c->d_nodes = nullptr; c->n_slots = 0; }
+    VR_HIP(hipMalloc((void **)&c->d_nodes, n_slots * sizeof(uint32_t)));
+    VR_HIP(hipMemcpy(c->d_nodes, nodes, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->n_slots = n_slots;
+    c->root_dim[0] = root_dim[0]; c->root_dim[1] = root_dim[1]; c->root_dim[2] = root_dim[2];
+    return VR_OK;
+}
+
+int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
+{
+    if (!c) return VR_EARG;
+    if (!c->h_vox) return VR_ESTATE;
+    uint32_t *nodes = nullptr;
+    uint64_t n_slots = 0;
+    uint8_t rd[3];
+    int rc = vr_host_build_kdt(c->h_vox, c->res, heuristic, 0, &nodes, &n_slots, rd, stats_out);
+    if (rc != VR_OK) return rc;
+    rc = vr_upload_kdt(c, nodes, n_slots, rd);
+    vr_free(nodes);
+    return rc;
+}
+
+int vr_download_kdt(vr_ctx *c, uint32_t *nodes_out, uint64_t cap_slots, uint64_t *n_slots_out, uint8_t root_dim_out[3])
+{
+    if (!c) return VR_EARG;
+    if (!c->d_nodes) return VR_ESTATE;
+    if (n_slots_out) *n_slots_out = c->n_slots;
+    if (root_dim_out) { root_dim_out[0] = c->root_dim[0]; root_dim_out[1] = c->root_dim[1]; root_dim_out[2] = c->root_dim[2]; }
+    if (nodes_out) {
+        if (cap_slots < c->n_slots) return VR_EARG;
+        VR_HIP(hipSetDevice(c->device));
+        VR_HIP(hipMemcpy(nodes_out, c->d_nodes, c->n_slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return VR_OK;
+}
+
+int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
+                     uint32_t row_end, void *d_rgb24, void *d_stats, const vr_taps *d_taps, void *stream)
+{
+    if (!c || !d_rgb24) return VR_EARG;
+    int rc = check_view(view);
+    if (rc != VR_OK) return rc;
+    if (!c->d_nodes) return VR_ESTATE;
+    if (iso_count == 0 || iso_count > 65535u || iso_begin > 255u || iso_begin + iso_count > 256u) return VR_EARG;
+    if (row_begin >= row_end || row_end > view->height) return VR_EARG;
+    VR_HIP(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    VrViewK k = make_view(c, view);
+    VrTapsK taps = { nullptr, nullptr, nullptr, nullptr };
+    if (d_taps) {
+        taps.cell_flag = d_taps->cell_flag;
+        taps.t = d_taps->t;
+        taps.checked = d_taps->checked;
+        taps.node = d_taps->node;
+    }
+    if (d_stats) VR_HIP(hipMemsetAsync(d_stats, 0, sizeof(vr_render_stats) * iso_count, s));
+    if (c->timing) {
+        while (c->ev.size() < c->ev_used + 2) {
+            hipEvent_t e;
+            VR_HIP(hipEventCreate(&e));
+            c->ev.push_back(e);
+        }
+        VR_HIP(hipEventRecord(c->ev[c->ev_used], s));
+    }
+    VR_HIP(vr_launch_render(c->variant == VR_KERNEL_DEFAULT ? VR_KERNEL_RESUME : c->variant, s, k, c->d_nodes, iso_begin,
+                            iso_count, row_begin, row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps));
+    if (c->timing) {
+        VR_HIP(hipEventRecord(c->ev[c->ev_used + 1], s));
+        c->ev_used += 2;
+    }
+    return VR_OK;
+}
+
+int vr_render_sweep(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint8_t *rgb24_out,
+                    vr_render_stats *stats_out, const vr_taps *taps)
+{
+    if (!c || !rgb24_out) return VR_EARG;
+    int rc = check_view(view);
+    if (rc != VR_OK) return rc;
+    if (!c->d_nodes) return VR_ESTATE;
+    if (iso_count == 0 || iso_begin > 255u || iso_begin + iso_count > 256u) return VR_EARG;
+    VR_HIP(hipSetDevice(c->device));
+    const size_t npix = (size_t)view->width * view->height * iso_count;
+    rc = ensure((void **)&c->d_rgb, &c->rgb_cap, npix * 3);
+    if (rc != VR_OK) return rc;
+    rc = ensure((void **)&c->d_stats, &c->stats_cap, sizeof(vr_render_stats) * iso_count);
+    if (rc != VR_OK) return rc;
+    vr_taps dt = { nullptr, nullptr, nullptr, nullptr };
+    void *host_tap[4] = { nullptr, nullptr, nullptr, nullptr };
+    if (taps) {
+        host_tap[0] = taps->cell_flag; host_tap[1] = taps->t; host_tap[2] = taps->checked; host_tap[3] = taps->node;
+        for (int i = 0; i < 4; i++)
+            if (host_tap[i]) {
+                rc = ensure(&c->d_tap[i], &c->tap_cap[i], npix * 4);
+                if (rc != VR_OK) return rc;
+            }
+        dt.cell_flag = host_tap[0] ? (uint32_t *)c->d_tap[0] : nullptr;
+        dt.t = host_tap[1] ? (float *)c->d_tap[1] : nullptr;
+        dt.checked = host_tap[2] ? (uint32_t *)c->d_tap[2] : nullptr;
+        dt.node = host_tap[3] ? (uint32_t *)c->d_tap[3] : nullptr;
+    }
+    rc = vr_render_device(c, view, iso_begin, iso_count, 0, view->height, c->d_rgb, c->d_stats, &dt, c->stream);
+    if (rc != VR_OK) return rc;
+    VR_HIP(hipMemcpyAsync(rgb24_out, c->d_rgb, npix * 3, hipMemcpyDeviceToHost, c->stream));
+    if (stats_out)
+        VR_HIP(hipMemcpyAsync(stats_out, c->d_stats, sizeof(vr_render_stats) * iso_count, hipMemcpyDeviceToHost, c->stream));
+    for (int i = 0; i < 4; i++)
+        if (host_tap[i]) VR_HIP(hipMemcpyAsync(host_tap[i], c->d_tap[i], npix * 4, hipMemcpyDeviceToHost, c->stream));
+    VR_HIP(hipStreamSynchronize(c->stream));
+    return VR_OK;
+}
+
+int vr_render(vr_ctx *c, const vr_view *view, uint8_t isoval, uint8_t *rgb24_out, vr_render_stats *stats_out,
+              const vr_taps *taps)
+{
+    return vr_render_sweep(c, view, isoval, 1, rgb24_out, stats_out, taps);
+}
+
+int vr_sync(vr_ctx *c)
+{
+    if (!c) return VR_EARG;
+    VR_HIP(hipSetDevice(c->device));
+    VR_HIP(hipStreamSynchronize(c->stream));
+    return VR_OK;
+}
+
+int vr_set_timing(vr_ctx *c, int enabled)
+{
+    if (!c) return VR_EARG;
+    c->timing = enabled ? 1 : 0;
+    return VR_OK;
+}
+
+int vr_timing_read(vr_ctx *c, double *total_ms_out, uint32_t *launches_out)
+{
+    if (!c || !total_ms_out || !launches_out) return VR_EARG;
+    VR_HIP(hipSetDevice(c->device));
+    double total = 0.0;
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0.0f;
+        VR_HIP(hipEventSynchronize(c->ev[i + 1]));
+        VR_HIP(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        total += ms;
+    }
+    *total_ms_out = total;
+    *launches_out = (uint32_t)(c->ev_used / 2);
+    c->ev_used = 0;
+    return VR_OK;
+}
+
+int vr_set_kernel(vr_ctx *c, int variant)
+{
+    if (!c || variant < 0 || variant >= VR_KERNEL_COUNT) return VR_EARG;
+    c->variant = variant;
+    return VR_OK;
+}
+
+const char *vr_kernel_name(int variant)
+{
+    switch (variant) {
+    case VR_KERNEL_DEFAULT: return "default";
+    case VR_KERNEL_RESTART_GLOBAL: return "restart-global";
+    case VR_KERNEL_RESTART_LDS: return "restart-lds";
+    case VR_KERNEL_RESUME: return "resume";
+    default: return nullptr;
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,295 @@
+/*
+ * vr_host.cpp -- host-side producers of the ray-casting path: the .vol loader, the SlimKDT
+ * builder and the reference driver's camera.  No GPU code.  Built with -ffp-contract=off so
+ * the camera arithmetic matches the reference's strict f32.
+ *
+ *   vr_load_ucd        Data.loadUCD                       src/Data.zig:9-44
+ *   vr_host_build_kdt  SlimKDT.newHeursiticPartition      src/SlimKDT.zig:222-322, heuristics :327-598
+ *   vr_main_camera     camera set-up of the driver        src/main.zig:31-43
+ *
+ * The builder does not scan every cell of a node's box per split candidate the way the reference
+ * does (src/SlimKDT.zig:275-298, :327-357).  It uses two identities that give the same numbers:
+ *   * a node's density range is the union of its children's ranges (the child boxes share the
+ *     voxel plane at the partition, so together they cover exactly the parent's voxels), hence
+ *     ranges are produced bottom-up from the 8-corner range of each leaf cell;
+ *   * for a split candidate p the left/right ranges are prefix/suffix min/max over per-plane
+ *     ("slab") ranges along the split axis, so all candidates of a node cost one pass over its
+ *     voxels.
+ */
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/vr.h"
+
+namespace {
+
+struct Box {
+    uint8_t lo[3], hi[3];
+    uint32_t len(int a) const { return (uint32_t)(uint8_t)(hi[a] - lo[a]); }
+    uint32_t size() const { return len(0) * len(1) * len(2); } /* src/geo.zig:315-317 */
+    int largest_dim() const                                     /* src/geo.zig:319-327 */
+    {
+        if (len(0) > len(1) && len(0) > len(2)) return 0;
+        if (len(1) > len(2)) return 1;
+        return 2;
+    }
+};
+
+struct MinMax {
+    uint8_t mn, mx;
+    void merge(MinMax o)
+    {
+        if (o.mn < mn) mn = o.mn;
+        if (o.mx > mx) mx = o.mx;
+    }
+};
+
+struct Builder {
+    const uint8_t *vox;
+    uint32_t res[3];
+    uint64_t sx, sy; /* strides of x and y in the voxel array (z stride is 1), src/Data.zig:90-92 */
+    std::vector<uint32_t> nodes;
+    uint64_t max_slots;
+    int heuristic;
+    int err;
+    vr_build_stats stats;
+
+    /* is the span heuristic (src/SlimKDT.zig:327-357) the one consulted at this layer, and with
+     * which deviation weight?  Otherwise AlwaysCenterH (:359-367) decides. */
+    bool span_active(uint32_t layer, float *weight) const
+    {
+        *weight = 1.0f;
+        switch (heuristic) {
+        case VR_H_ALWAYS_CENTER: return false;
+        case VR_H_MINIMIZE_SPAN: return true;
+        case VR_H_FLEXIBLE_FIRST5: return layer < 5;
+        case VR_H_FLEXIBLE_FIRST10: return layer < 10;
+        case VR_H_FLEXIBLE_AFTER10: return layer > 10;
+        case VR_H_FLEXIBLE_AFTER15: return layer > 15;
+        case VR_H_FLEXIBLE_AFTER20: return layer > 20;
+        case VR_H_FLEXIBLE_CENTER_WEIGHTED5: *weight = 5.0f; return true;
+        case VR_H_FLEXIBLE_CENTER_WEIGHTED10: *weight = 10.0f; return true;
+        case VR_H_FLEXIBLE_CENTER_WEIGHTED30: *weight = 30.0f; return true;
+        case VR_H_FLEXIBLE_CENTER_WEIGHTED50: *weight = 50.0f; return true;
+        case VR_H_FLEXIBLE_CENTER_WEIGHTED75: *weight = 75.0f; return true;
+        default: *weight = 100.0f; return true;
+        }
+    }
+
+    /* per-plane density range along `axis` over the voxels [lo..hi] (inclusive) of the box */
+    void slab_ranges(const Box &b, int axis, MinMax *slab) const
+    {
+        for (uint32_t s = b.lo[axis]; s <= b.hi[axis]; s++) { slab[s].mn = 255; slab[s].mx = 0; }
+        for (uint32_t x = b.lo[0]; x <= b.hi[0]; x++)
+            for (uint32_t y = b.lo[1]; y <= b.hi[1]; y++) {
+                const uint8_t *row = vox + x * sx + y * sy;
+                if (axis == 2) {
+                    for (uint32_t z = b.lo[2]; z <= b.hi[2]; z++) {
+                        uint8_t v = row[z];
+                        if (v < slab[z].mn) slab[z].mn = v;
+                        if (v > slab[z].mx) slab[z].mx = v;
+                    }
+                } else {
+                    uint8_t mn = 255, mx = 0;
+                    for (uint32_t z = b.lo[2]; z <= b.hi[2]; z++) {
+                        uint8_t v = row[z];
+                        if (v < mn) mn = v;
+                        if (v > mx) mx = v;
+                    }
+                    uint32_t s = axis == 0 ? x : y;
+                    if (mn < slab[s].mn) slab[s].mn = mn;
+                    if (mx > slab[s].mx) slab[s].mx = mx;
+                }
+            }
+    }
+
+    /* src/SlimKDT.zig:286-298: first candidate in min+1 .. max-1 with the strictly smallest score */
+    uint8_t choose_partition(const Box &b, int axis, uint8_t mid, uint32_t layer) const
+    {
+        uint32_t lo = b.lo[axis], hi = b.hi[axis];
+        if (lo + 1 >= hi) return mid; /* no candidate: the initial value stands (:286) */
+        float weight;
+        if (!span_active(layer, &weight)) return mid; /* score 0 at mid, 1 elsewhere: mid is in range and wins */
+        MinMax slab[256], pre[256], suf[256];
+        slab_ranges(b, axis, slab);
+        pre[lo] = slab[lo];
+        for (uint32_t s = lo + 1; s <= hi; s++) { pre[s] = pre[s - 1]; pre[s].merge(slab[s]); }
+        suf[hi] = slab[hi];
+        for (uint32_t s = hi; s-- > lo;) { suf[s] = suf[s + 1]; suf[s].merge(slab[s]); }
+        uint8_t best = mid;
+        float best_h = INFINITY;
+        for (uint32_t p = lo + 1; p < hi; p++) {
+            /* left half holds cells [lo,p) = voxels lo..p ; right half cells [p,hi) = voxels p..hi */
+            float h = 0;
+            h += std::fabs((float)p - (float)mid) * weight;
+            h += std::fabs((float)pre[p].mx - (float)pre[p].mn);
+            h += std::fabs((float)suf[p].mx - (float)suf[p].mn);
+            if (best_h > h) { best = (uint8_t)p; best_h = h; }
+        }
+        return best;
+    }
+
+    bool ensure_slot(uint64_t idx)
+    {
+        if (idx < nodes.size()) return true;
+        if (idx >= max_slots) { err = VR_ETOODEEP; return false; } /* the realloc of :266-270 fails */
+        uint64_t ncap = nodes.size();
+        while (idx >= ncap) ncap *= 2;
+        if (ncap > max_slots) ncap = max_slots;
+        try {
+            nodes.resize(ncap, 0u);
+        } catch (const std::bad_alloc &) {
+            err = VR_ENOMEM;
+            return false;
+        }
+        return true;
+    }
+
+    /* src/SlimKDT.zig:248-322, children by SpaceTracker.leftHalf/rightHalf (:66-88) */
+    MinMax build(const Box &b, uint64_t idx, uint32_t layer, uint64_t *non_center, uint64_t *layers, uint64_t *count)
+    {
+        MinMax r = { 255, 0 };
+        if (err) return r;
+        if (b.size() < 1) return r; /* :257-259: an empty half adds no node */
+        if (!ensure_slot(idx)) return r;
+        int axis = b.largest_dim();
+        uint8_t mid = (uint8_t)(((uint32_t)b.lo[axis] + (uint32_t)b.hi[axis]) / 2);
+        if (b.size() == 1) {
+            for (int k = 0; k < 8; k++) {
+                uint8_t v = vox[(b.lo[0] + (k & 1)) * sx + (b.lo[1] + ((k >> 1) & 1)) * sy + (b.lo[2] + ((k >> 2) & 1))];
+                if (v < r.mn) r.mn = v;
+                if (v > r.mx) r.mx = v;
+            }
+            nodes[idx] = (uint32_t)r.mn | ((uint32_t)r.mx << 8) | ((uint32_t)mid << 16) | ((uint32_t)axis << 24);
+            *count += 1;
+            if (layer > *layers) *layers = layer;
+            return r;
+        }
+        uint8_t part = choose_partition(b, axis, mid, layer);
+        Box l = b, rr = b;
+        if (part < l.hi[axis]) l.hi[axis] = part;   /* src/geo.zig:256-275 */
+        if (part > rr.lo[axis]) rr.lo[axis] = part;
+        r = build(l, 2 * idx + 1, layer + 1, non_center, layers, count);
+        MinMax r2 = build(rr, 2 * idx + 2, layer + 1, non_center, layers, count);
+        if (err) return r;
+        r.merge(r2);
+        nodes[idx] = (uint32_t)r.mn | ((uint32_t)r.mx << 8) | ((uint32_t)part << 16) | ((uint32_t)axis << 24);
+        *count += 1;
+        *non_center += (mid != part);
+        if (layer > *layers) *layers = layer;
+        return r;
+    }
+};
+
+uint32_t be32(const uint8_t *p)
+{
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+} // namespace
+
+extern "C" {
+
+const char *vr_strerror(int code)
+{
+    switch (code) {
+    case VR_OK: return "ok";
+    case VR_EARG: return "invalid argument";
+    case VR_ENOMEM: return "out of host memory";
+    case VR_ESTATE: return "no volume / tree on the device yet";
+    case VR_ETOODEEP: return "tree exceeds the node slot limit (FAILD TO BUILD KDT)";
+    case VR_EIO: return "cannot read file";
+    case VR_EFORMAT: return "malformed .vol file";
+    case VR_ENODEVICE: return "no gfx950 HIP device";
+    default: return code <= VR_EHIP_BASE ? "HIP runtime error (code = VR_EHIP_BASE - hipError_t)" : "unknown error";
+    }
+}
+
+int vr_load_ucd(const char *path, uint8_t **vox_out, uint32_t res_out[3])
+{
+    if (!path || !vox_out || !res_out) return VR_EARG;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return VR_EIO;
+    uint8_t hdr[28]; /* 3 x u32 BE dims, 1 unused u32, 3 x 4 bytes "true size" (ignored), src/Data.zig:17-27 */
+    if (std::fread(hdr, 1, sizeof hdr, f) != sizeof hdr) { std::fclose(f); return VR_EFORMAT; }
+    uint32_t r[3] = { be32(hdr), be32(hdr + 4), be32(hdr + 8) };
+    uint64_t n = (uint64_t)r[0] * r[1] * r[2];
+    if (n == 0 || n > ((uint64_t)1 << 36)) { std::fclose(f); return VR_EFORMAT; }
+    uint8_t *v = (uint8_t *)std::malloc(n);
+    if (!v) { std::fclose(f); return VR_ENOMEM; }
+    /* the file body is already in x-major / z-fastest order (src/Data.zig:30-41 with :94-96) */
+    if (std::fread(v, 1, n, f) != n) { std::free(v); std::fclose(f); return VR_EFORMAT; }
+    std::fclose(f);
+    *vox_out = v;
+    res_out[0] = r[0]; res_out[1] = r[1]; res_out[2] = r[2];
+    return VR_OK;
+}
+
+int vr_host_build_kdt(const uint8_t *vox, const uint32_t res[3], int heuristic, uint64_t max_slots,
+                      uint32_t **nodes_out, uint64_t *n_slots_out, uint8_t root_dim_out[3], vr_build_stats *stats_out)
+{
+    if (!vox || !res || !nodes_out || !n_slots_out || !root_dim_out) return VR_EARG;
+    if (heuristic < 0 || heuristic >= VR_H_COUNT) return VR_EARG;
+    for (int a = 0; a < 3; a++)
+        if (res[a] < 2 || res[a] > 256) return VR_EARG; /* SPACESIZE = u8 (src/typedef.zig:1): root_dim = res-1 <= 255 */
+    Builder b;
+    b.vox = vox;
+    b.res[0] = res[0]; b.res[1] = res[1]; b.res[2] = res[2];
+    b.sx = (uint64_t)res[1] * res[2];
+    b.sy = res[2];
+    b.max_slots = max_slots ? max_slots : ((uint64_t)1 << 32);
+    b.heuristic = heuristic;
+    b.err = 0;
+    uint64_t cap = 1;
+    uint64_t want = (uint64_t)res[0] * res[1] * res[2] * 2; /* src/SlimKDT.zig:139 */
+    while (cap < want) cap *= 2;
+    if (cap > b.max_slots) cap = b.max_slots;
+    try {
+        b.nodes.assign(cap, 0u);
+    } catch (const std::bad_alloc &) {
+        return VR_ENOMEM;
+    }
+    Box root;
+    for (int a = 0; a < 3; a++) { root.lo[a] = 0; root.hi[a] = (uint8_t)(res[a] - 1); }
+    uint64_t non_center = 0, layers = 0, count = 0;
+    b.build(root, 0, 0, &non_center, &layers, &count);
+    if (b.err) return b.err;
+    /* keep the smallest power of two that holds every used slot */
+    uint64_t used = (uint64_t)1 << (layers + 1);
+    if (used > b.nodes.size()) used = b.nodes.size();
+    uint32_t *out = (uint32_t *)std::malloc(used * sizeof(uint32_t));
+    if (!out) return VR_ENOMEM;
+    std::memcpy(out, b.nodes.data(), used * sizeof(uint32_t));
+    *nodes_out = out;
+    *n_slots_out = used;
+    for (int a = 0; a < 3; a++) root_dim_out[a] = (uint8_t)(res[a] - 1);
+    if (stats_out) {
+        stats_out->non_center_partition_count = non_center;
+        stats_out->layer_count = layers;
+        stats_out->number_of_nodes = count;
+    }
+    return VR_OK;
+}
+
+void vr_main_camera(const uint32_t res[3], const float pos[3], float forw_out[3], float up_out[3])
+{
+    /* data_center = f32(res / 2) with integer division, src/main.zig:31-35 */
+    float c[3] = { (float)(res[0] / 2), (float)(res[1] / 2), (float)(res[2] / 2) };
+    float d[3] = { c[0] - pos[0], c[1] - pos[1], c[2] - pos[2] };
+    float len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); /* src/geo.zig:111-113 */
+    float inv = 1.0f / len;                                         /* src/geo.zig:123-125 */
+    float f[3] = { d[0] * inv, d[1] * inv, d[2] * inv };
+    /* c = forw x (0,1,0) ; up = c x forw   (src/main.zig:40-43, cross: src/geo.zig:115-121) */
+    float w[3] = { 0.0f, 1.0f, 0.0f };
+    float a[3] = { f[1] * w[2] - f[2] * w[1], f[2] * w[0] - f[0] * w[2], f[0] * w[1] - f[1] * w[0] };
+    float u[3] = { a[1] * f[2] - a[2] * f[1], a[2] * f[0] - a[0] * f[2], a[0] * f[1] - a[1] * f[0] };
+    for (int k = 0; k < 3; k++) { forw_out[k] = f[k]; up_out[k] = u[k]; }
+}
+
+void vr_free(void *p) { std::free(p); }
+
+} // extern "C"

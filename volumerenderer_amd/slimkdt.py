@@ -1,0 +1,46 @@
+"""SlimKDT: the min/max KD-tree over cells the ray caster walks (src/SlimKDT.zig)."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class SlimKDT:
+    """nodes: uint32 heap-indexed array of packed SlimNode words (src/SlimKDT.zig:9-13);
+    root_dim: uint8[3] = resolution - 1 (:129-133); build: PartitionBuildData (:215-219)."""
+
+    def __init__(self, nodes, root_dim, build=None, data=None):
+        self.nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+        self.root_dim = np.ascontiguousarray(root_dim, dtype=np.uint8)
+        self.build = build
+        self.data = data
+
+    @staticmethod
+    def left(i):
+        return 2 * i + 1  # src/SlimKDT.zig:24-26
+
+    @staticmethod
+    def right(i):
+        return 2 * i + 2  # src/SlimKDT.zig:28-30
+
+    @staticmethod
+    def parent(i):
+        return (i - 1) // 2  # src/SlimKDT.zig:32-34
+
+    @staticmethod
+    def newHeursiticPartition(data, heuristic="AlwaysCenter", max_slots=0):
+        """src/SlimKDT.zig:222-246, built on the host by libvr_hip.so.  Raises VrError(VR_ETOODEEP) where the
+        reference prints "FAILD TO BUILD KDT"."""
+        L = capi.lib()
+        h = capi.HEURISTICS[heuristic] if isinstance(heuristic, str) else int(heuristic)
+        res = (C.c_uint32 * 3)(*data.resulution)
+        p = C.POINTER(C.c_uint32)()
+        n = C.c_uint64()
+        rd = (C.c_uint8 * 3)()
+        st = capi.BuildStats()
+        capi.check(L.vr_host_build_kdt(data.data.ctypes.data, res, h, max_slots, C.byref(p), C.byref(n), rd,
+                                       C.byref(st)), "vr_host_build_kdt")
+        nodes = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+        L.vr_free(p)
+        return SlimKDT(nodes, np.array(list(rd), dtype=np.uint8), st, data)
