@@ -42,9 +42,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
 def cpu_baseline(kdt, pos, forw, up, width, budget_s=20.0):
-    """Times the oracle's render_image (1 core) on every 16th iso of the sweep until the budget is spent."""
+    """Times the oracle's render_image (1 core) on every 4th iso of the sweep until the budget is spent."""
     from oracle import oracle as O
-    isos = list(range(0, 256, 16))
+    isos = list(range(0, 256, 4))
     done, rays, checks = [], 0, 0
     t0 = time.perf_counter()
     for iso in isos:

@@ -34,6 +34,8 @@ extern "C" {
 #define VR_EIO (-5)       /* file could not be read                                               */
 #define VR_EFORMAT (-6)   /* malformed .vol file                                                  */
 #define VR_ENODEVICE (-7) /* no usable HIP device / the device is not gfx950                      */
+#define VR_ETREE (-8)     /* uploaded tree is malformed: a reachable node lies outside the array,  */
+                          /* or an inner node's partition is not strictly inside its box          */
 #define VR_EHIP_BASE (-1000) /* VR_EHIP_BASE - hipError_t                                         */
 
 /* Per-pixel flag stored in bits 24..31 of a cell/flag tap word. */
@@ -117,6 +119,16 @@ int vr_host_build_kdt(const uint8_t *vox, const uint32_t res[3], int heuristic, 
                       uint32_t **nodes_out, uint64_t *n_slots_out, uint8_t root_dim_out[3],
                       vr_build_stats *stats_out);
 
+/* The flattening step in front of the GPU: walks the heap-indexed SlimNode array from the root with
+ * the boxes SpaceTracker would hold (src/SlimKDT.zig:55-103), checks that every reachable node lies
+ * inside the array and that every inner node's partition is strictly inside its box (what the
+ * reference's builder always produces; anything else never reaches a leaf in the reference's zoom
+ * either), and writes the word the kernels read: bits 0-23 unchanged (min, max, partition), bits
+ * 24-28 = axis * 10, bit 31 = leaf (box of one cell).  prepared_out has n_slots words.  Returns
+ * VR_ETREE for a malformed tree.  max_depth_out = deepest level (root = 0). */
+int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3],
+                        uint32_t *prepared_out, uint32_t *max_depth_out, uint64_t *n_nodes_out);
+
 /* Camera of the reference driver (src/main.zig:31-43): forw = norm(f32(res/2) - pos),
  * up = (forw x (0,1,0)) x forw (not normalised). */
 void vr_main_camera(const uint32_t res[3], const float pos[3], float forw_out[3], float up_out[3]);
@@ -135,7 +147,8 @@ void vr_ctx_destroy(vr_ctx *ctx);
 int vr_upload_volume(vr_ctx *ctx, const uint8_t *vox, uint32_t rx, uint32_t ry, uint32_t rz);
 
 /* Uploads SlimKDT.nodes verbatim (src/SlimKDT.zig:17) with root_dim (:15).  Bits 26..31 of each
- * word are ignored (undefined in the Zig packed struct). */
+ * word are ignored (undefined in the Zig packed struct).  The array is validated and flattened
+ * with vr_host_prepare_kdt first: VR_ETREE for a tree the reference could not traverse either. */
 int vr_upload_kdt(vr_ctx *ctx, const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3]);
 
 /* SlimKDT.newHeursiticPartition on the uploaded volume, result kept on the device.

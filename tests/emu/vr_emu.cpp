@@ -14,12 +14,14 @@ struct HostFetch {
     uint32_t operator()(uint32_t i) const { return nodes[i]; }
 };
 struct HostStack {
-    uint16_t rec[VR_MAX_DEPTH + 1];
-    void push(uint32_t level, uint32_t r) { rec[level] = (uint16_t)r; }
-    uint32_t pop(uint32_t level) const { return rec[level]; }
+    uint32_t word[VR_MAX_DEPTH + 1];
+    void push(uint32_t level, uint32_t w) { word[level] = w; }
+    uint32_t pop(uint32_t level) const { return word[level]; }
 };
 } // namespace
 
+/* variant 1 walks the reference's SlimNode array; any other variant walks the PREPARED array
+ * (vr_host_prepare_kdt of the product library) with the resume traversal */
 extern "C" int vr_emu_render(int variant, const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3],
                              const float src[3], const float forw[3], const float up[3], uint32_t width,
                              uint32_t height, float viewport_width, uint32_t iso, uint8_t *rgb, uint32_t *cell_flag,

@@ -3,8 +3,23 @@ import ctypes as C
 import numpy as np
 
 
+def prepare_nodes(nodes, rd):
+    """vr_host_prepare_kdt of the product library (host-only): validated, flattened node words."""
+    from volumerenderer_amd import capi
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+    out = np.zeros_like(nodes)
+    depth = C.c_uint32()
+    count = C.c_uint64()
+    rc = capi.lib().vr_host_prepare_kdt(nodes.ctypes.data, len(nodes), (C.c_uint8 * 3)(*[int(x) for x in rd]),
+                                        out.ctypes.data, C.byref(depth), C.byref(count))
+    return rc, out, depth.value, count.value
+
+
 def emu_render(L, variant, nodes, rd, pos, f, u, w, h, vp, iso):
     """Runs the kernels' lane code on the CPU (tests/emu/vr_emu.cpp)."""
+    if variant != 1:
+        rc, nodes, _, _ = prepare_nodes(nodes, rd)
+        assert rc == 0
     rgb = np.zeros((h, w, 3), np.uint8)
     cf = np.zeros((h, w), np.uint32)
     tt = np.zeros((h, w), np.float32)

@@ -13,7 +13,7 @@ from helpers import assert_same_render, random_volume
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [capi.KERNEL_RESTART_GLOBAL, capi.KERNEL_RESTART_LDS, capi.KERNEL_RESUME]
+VARIANTS = [capi.KERNEL_RESTART_GLOBAL, capi.KERNEL_RESTART_LDS, capi.KERNEL_RESUME, capi.KERNEL_PIPELINE]
 
 
 @pytest.fixture(scope="module")
@@ -124,7 +124,7 @@ def test_skull_sweep_properties_at_full_size(oracle, skull_vox, skull_renderer):
         assert ((g == 0) | (g >= 55)).all() and (g[flags[k] != capi.FLAG_HIT] == 0).all()
     single = _gpu(skull_renderer, pos, forw, up, 1024, 1024, 2.0, 80)
     assert (single["rgb"] == out["rgb"][4]).all() and (single["checked"] == out["checked"][4]).all()
-    for variant in (capi.KERNEL_RESTART_LDS,):
+    for variant in (capi.KERNEL_RESTART_LDS, capi.KERNEL_RESUME):
         skull_renderer.set_kernel(variant)
         other = _gpu(skull_renderer, pos, forw, up, 1024, 1024, 2.0, 80)
         skull_renderer.set_kernel(capi.KERNEL_DEFAULT)
@@ -230,6 +230,9 @@ def test_error_paths_on_device(c60_tree):
         assert L.vr_render(r.handle, C.byref(v), 0, buf.ctypes.data, None, None) == capi.VR_EARG
         assert L.vr_set_kernel(r.handle, 77) == capi.VR_EARG
         assert L.vr_upload_kdt(r.handle, nodes.ctypes.data, 0, (C.c_uint8 * 3)(1, 1, 1)) == capi.VR_EARG
+        bad = nodes.copy()
+        bad[0] = bad[0] & ~np.uint32(0x00FF0000)  # root partition on the box edge: never reaches a leaf
+        assert L.vr_upload_kdt(r.handle, bad.ctypes.data, len(bad), (C.c_uint8 * 3)(*rd)) == capi.VR_ETREE
 
 
 def test_build_on_context_and_download(oracle, c60_vox, c60_tree):

@@ -102,3 +102,28 @@ def test_main_camera_matches_oracle(oracle):
             b = oracle.main_camera(res, pos)
             for x, y in zip(a, b):
                 assert (x.view(np.uint32) == y.view(np.uint32)).all()
+
+
+def test_prepare_kdt_flattens_and_validates(oracle, c60_tree):
+    from helpers import prepare_nodes
+    nodes, rd, st = c60_tree
+    rc, prep, depth, count = prepare_nodes(nodes, rd)
+    assert rc == 0 and depth == st.layer_count and count == st.number_of_nodes
+    assert ((prep & 0x00FFFFFF) == (nodes & 0x00FFFFFF)).all()          # min, max, partition untouched
+    used = prep != 0
+    leaf = (prep >> 31) == 1
+    assert int(leaf.sum()) == 63 ** 3                                    # one leaf per cell
+    inner = used & ~leaf
+    assert (((prep[inner] >> 24) & 31) == 10 * ((nodes[inner] >> 24) & 3)).all()
+    # undefined upper bits of the Zig packed struct are ignored
+    noisy = nodes | (np.uint32(0xFC) << 24)
+    rc2, prep2, _, _ = prepare_nodes(noisy, rd)
+    assert rc2 == 0 and (prep2 == prep).all()
+    # malformed trees are rejected: partition on the box edge, bad axis, truncated array
+    bad = nodes.copy(); bad[0] = (bad[0] & ~np.uint32(0x00FF0000)) | (np.uint32(63) << 16)
+    assert prepare_nodes(bad, rd)[0] == capi.VR_ETREE
+    bad = nodes.copy(); bad[0] = bad[0] & ~np.uint32(0x00FF0000)
+    assert prepare_nodes(bad, rd)[0] == capi.VR_ETREE
+    bad = nodes.copy(); bad[5] |= np.uint32(3 << 24)
+    assert prepare_nodes(bad, rd)[0] == capi.VR_ETREE
+    assert prepare_nodes(nodes[: len(nodes) // 4], rd)[0] == capi.VR_ETREE

@@ -11,10 +11,11 @@ LIB_PATH = os.path.join(_HERE, "libvr_hip.so")
 
 VR_OK = 0
 VR_EARG, VR_ENOMEM, VR_ESTATE, VR_ETOODEEP, VR_EIO, VR_EFORMAT, VR_ENODEVICE = -1, -2, -3, -4, -5, -6, -7
+VR_ETREE = -8
 VR_EHIP_BASE = -1000
 FLAG_MISS, FLAG_HIT, FLAG_OOB = 0, 1, 2
 
-KERNEL_DEFAULT, KERNEL_RESTART_GLOBAL, KERNEL_RESTART_LDS, KERNEL_RESUME = 0, 1, 2, 3
+KERNEL_DEFAULT, KERNEL_RESTART_GLOBAL, KERNEL_RESTART_LDS, KERNEL_RESUME, KERNEL_PIPELINE = 0, 1, 2, 3, 4
 
 HEURISTICS = {
     "AlwaysCenter": 0,
@@ -34,7 +35,7 @@ HEURISTICS = {
 
 # every symbol include/vr.h declares; tests check that the library exports each of them
 EXPORTS = [
-    "vr_strerror", "vr_load_ucd", "vr_host_build_kdt", "vr_main_camera", "vr_free", "vr_ctx_create",
+    "vr_strerror", "vr_load_ucd", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_main_camera", "vr_free", "vr_ctx_create",
     "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_render",
     "vr_render_sweep", "vr_render_device", "vr_sync", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
@@ -88,6 +89,7 @@ def lib():
     L.vr_load_ucd.argtypes = [C.c_char_p, C.POINTER(u8p), u32p]
     L.vr_host_build_kdt.argtypes = [vp, u32p, C.c_int, C.c_uint64, C.POINTER(u32p), C.POINTER(C.c_uint64), u8p,
                                     C.POINTER(BuildStats)]
+    L.vr_host_prepare_kdt.argtypes = [vp, C.c_uint64, u8p, vp, u32p, C.POINTER(C.c_uint64)]
     L.vr_main_camera.argtypes = [u32p, f32p, f32p, f32p]
     L.vr_main_camera.restype = None
     L.vr_free.argtypes = [vp]

@@ -25,9 +25,15 @@ struct vr_ctx {
     uint32_t res[3] = { 0, 0, 0 };
     uint8_t *h_vox = nullptr; /* host copy for the host-side builder */
     /* tree */
-    uint32_t *d_nodes = nullptr;
+    uint32_t *d_nodes = nullptr;      /* SlimKDT.nodes as the reference lays them out          */
+    uint32_t *d_prepared = nullptr;   /* the validated, flattened form the fast kernels walk   */
     uint64_t n_slots = 0;
+    uint32_t max_depth = 0;
     uint8_t root_dim[3] = { 0, 0, 0 };
+    int n_cus = 0;
+    /* scratch of the pipeline kernels, grown on demand */
+    void *d_work = nullptr;
+    size_t work_cap = 0;
     /* staging for the host-buffer entry points, grown on demand */
     uint8_t *d_rgb = nullptr;
     size_t rgb_cap = 0;
@@ -99,6 +105,7 @@ int vr_ctx_create(int device, vr_ctx **out)
     vr_ctx *c = new (std::nothrow) vr_ctx();
     if (!c) return VR_ENOMEM;
     c->device = device;
+    c->n_cus = prop.multiProcessorCount;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -116,6 +123,8 @@ void vr_ctx_destroy(vr_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_vox) (void)hipFree(c->d_vox);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_prepared) (void)hipFree(c->d_prepared);
+    if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     if (c->d_stats) (void)hipFree(c->d_stats);
     for (int i = 0; i < 4; i++)
@@ -147,11 +156,24 @@ int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint
     if (!c || !nodes || !n_slots || !root_dim) return VR_EARG;
     if (n_slots > ((uint64_t)1 << 32)) return VR_EARG; /* heap indices are u32, src/SlimKDT.zig:24-34 */
     if (root_dim[0] == 0 || root_dim[1] == 0 || root_dim[2] == 0) return VR_EARG;
-    VR_HIP(hipSetDevice(c->device));
-    if (c->d_nodes) { VR_HIP(hipFree(c->d_nodes)); c->d_nodes = nullptr; c->n_slots = 0; }
-    VR_HIP(hipMalloc((void **)&c->d_nodes, n_slots * sizeof(uint32_t)));
-    VR_HIP(hipMemcpy(c->d_nodes, nodes, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice));
+    /* validate and flatten on the host before anything reaches the device */
+    uint32_t *prepared = (uint32_t *)std::malloc(n_slots * sizeof(uint32_t));
+    if (!prepared) return VR_ENOMEM;
+    uint32_t max_depth = 0;
+    int rc = vr_host_prepare_kdt(nodes, n_slots, root_dim, prepared, &max_depth, nullptr);
+    if (rc != VR_OK) { std::free(prepared); return rc; }
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
+    if (e == hipSuccess && c->d_prepared) { e = hipFree(c->d_prepared); c->d_prepared = nullptr; }
+    c->n_slots = 0;
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_nodes, n_slots * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_prepared, n_slots * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_prepared, prepared, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice);
+    std::free(prepared);
+    if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
     c->n_slots = n_slots;
+    c->max_depth = max_depth;
     c->root_dim[0] = root_dim[0]; c->root_dim[1] = root_dim[1]; c->root_dim[2] = root_dim[2];
     return VR_OK;
 }
@@ -203,21 +225,28 @@ int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_
         taps.checked = d_taps->checked;
         taps.node = d_taps->node;
     }
+    const int variant = c->variant == VR_KERNEL_DEFAULT ? VR_KERNEL_PIPELINE : c->variant;
+    if (variant == VR_KERNEL_PIPELINE) {
+        /* growing the scratch is the only allocation on this path; it happens when a larger view comes */
+        const size_t need = vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count);
+        if (need > c->work_cap) VR_HIP(hipStreamSynchronize(s));
+        rc = ensure(&c->d_work, &c->work_cap, need);
+        if (rc != VR_OK) return rc;
+    }
     if (d_stats) VR_HIP(hipMemsetAsync(d_stats, 0, sizeof(vr_render_stats) * iso_count, s));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->timing) {
         while (c->ev.size() < c->ev_used + 2) {
             hipEvent_t e;
             VR_HIP(hipEventCreate(&e));
             c->ev.push_back(e);
         }
-        VR_HIP(hipEventRecord(c->ev[c->ev_used], s));
+        ev0 = c->ev[c->ev_used];
+        ev1 = c->ev[c->ev_used + 1];
     }
-    VR_HIP(vr_launch_render(c->variant == VR_KERNEL_DEFAULT ? VR_KERNEL_RESUME : c->variant, s, k, c->d_nodes, iso_begin,
-                            iso_count, row_begin, row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps));
-    if (c->timing) {
-        VR_HIP(hipEventRecord(c->ev[c->ev_used + 1], s));
-        c->ev_used += 2;
-    }
+    VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
+                            row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, c->d_work, c->n_cus, ev0, ev1));
+    if (c->timing) c->ev_used += 2;
     return VR_OK;
 }
 
@@ -312,6 +341,7 @@ const char *vr_kernel_name(int variant)
     case VR_KERNEL_RESTART_GLOBAL: return "restart-global";
     case VR_KERNEL_RESTART_LDS: return "restart-lds";
     case VR_KERNEL_RESUME: return "resume";
+    case VR_KERNEL_PIPELINE: return "pipeline";
     default: return nullptr;
     }
 }

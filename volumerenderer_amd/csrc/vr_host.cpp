@@ -205,6 +205,7 @@ const char *vr_strerror(int code)
     case VR_EIO: return "cannot read file";
     case VR_EFORMAT: return "malformed .vol file";
     case VR_ENODEVICE: return "no gfx950 HIP device";
+    case VR_ETREE: return "malformed tree (a reachable node lies outside the array or does not split its box)";
     default: return code <= VR_EHIP_BASE ? "HIP runtime error (code = VR_EHIP_BASE - hipError_t)" : "unknown error";
     }
 }
@@ -288,6 +289,51 @@ void vr_main_camera(const uint32_t res[3], const float pos[3], float forw_out[3]
     float a[3] = { f[1] * w[2] - f[2] * w[1], f[2] * w[0] - f[0] * w[2], f[0] * w[1] - f[1] * w[0] };
     float u[3] = { a[1] * f[2] - a[2] * f[1], a[2] * f[0] - a[0] * f[2], a[0] * f[1] - a[1] * f[0] };
     for (int k = 0; k < 3; k++) { forw_out[k] = f[k]; up_out[k] = u[k]; }
+}
+
+int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], uint32_t *prepared_out,
+                        uint32_t *max_depth_out, uint64_t *n_nodes_out)
+{
+    if (!nodes || !n_slots || !root_dim || !prepared_out) return VR_EARG;
+    if (n_slots > ((uint64_t)1 << 32)) return VR_EARG;
+    if (root_dim[0] == 0 || root_dim[1] == 0 || root_dim[2] == 0) return VR_EARG;
+    std::memset(prepared_out, 0, n_slots * sizeof(uint32_t));
+    struct Item { uint64_t idx; Box box; uint32_t depth; };
+    std::vector<Item> todo;
+    todo.reserve(128);
+    Item root;
+    root.idx = 0; root.depth = 0;
+    for (int a = 0; a < 3; a++) { root.box.lo[a] = 0; root.box.hi[a] = root_dim[a]; }
+    todo.push_back(root);
+    uint32_t max_depth = 0;
+    uint64_t count = 0;
+    while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        if (it.idx >= n_slots) return VR_ETREE; /* a descent would read past the array */
+        const uint32_t n = nodes[it.idx];
+        const uint32_t axis = (n >> 24) & 3u, part = (n >> 16) & 0xffu;
+        count++;
+        if (it.depth > max_depth) max_depth = it.depth;
+        if (it.box.size() == 1) { /* leaf cell: src/raytrace.zig:178 */
+            prepared_out[it.idx] = (n & 0x00ffffffu) | 0x80000000u;
+            continue;
+        }
+        /* an inner node must split strictly inside its box, else a child is empty and the other one
+         * repeats its parent: the reference's zoom (src/SlimKDT.zig:90-103) would never reach a leaf */
+        if (axis > 2u || part <= it.box.lo[axis] || part >= it.box.hi[axis]) return VR_ETREE;
+        prepared_out[it.idx] = (n & 0x00ffffffu) | ((axis * 10u) << 24);
+        Item l = it, r = it;
+        l.idx = 2 * it.idx + 1; r.idx = 2 * it.idx + 2;
+        l.depth = r.depth = it.depth + 1;
+        l.box.hi[axis] = (uint8_t)part;
+        r.box.lo[axis] = (uint8_t)part;
+        todo.push_back(r);
+        todo.push_back(l);
+    }
+    if (max_depth_out) *max_depth_out = max_depth;
+    if (n_nodes_out) *n_nodes_out = count;
+    return VR_OK;
 }
 
 void vr_free(void *p) { std::free(p); }

@@ -20,13 +20,20 @@ enum {
     VR_KERNEL_DEFAULT = 0,
     VR_KERNEL_RESTART_GLOBAL = 1, /* literal root-restart loop, every node read from global memory     */
     VR_KERNEL_RESTART_LDS = 2,    /* root-restart loop, top tree levels staged in LDS                  */
-    VR_KERNEL_RESUME = 3,         /* path stack in LDS, resume from the lowest ancestor after a MOVE   */
-    VR_KERNEL_COUNT = 4
+    VR_KERNEL_RESUME = 3,         /* per-pixel threads, path stack in LDS, resume after a MOVE         */
+    VR_KERNEL_PIPELINE = 4,       /* compacted ray list + persistent waves with lane refill (default)  */
+    VR_KERNEL_COUNT = 5
 };
 
-/* Enqueues the traversal kernel: rows [row_begin,row_end) of iso_count frames. */
-hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes,
-                            uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end,
-                            uint8_t *d_rgb, vr_render_stats *d_stats, const VrTapsK &taps);
+/* Device scratch the pipeline variant needs for one call (ray list, tile offsets, queue heads). */
+size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count);
+
+/* Enqueues the kernels that render rows [row_begin,row_end) of iso_count frames.  d_nodes_raw is the
+ * reference's SlimNode array, d_nodes_prepared the flattened form of vr_host_prepare_kdt.  The
+ * dominant traversal kernel is bracketed by ev_begin / ev_end when they are not null. */
+hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_raw,
+                            const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
+                            uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
+                            const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end);
 
 #endif

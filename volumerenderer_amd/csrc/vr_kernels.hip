@@ -1,18 +1,32 @@
 /*
- * vr_kernels.hip -- gfx950 kernels of the isosurface ray caster: one primary ray per lane,
- * 8x8-pixel tiles per wave64 so the rays of a wave stay coherent.
+ * vr_kernels.hip -- gfx950 kernels of the isosurface ray caster (renderImage / traceRay,
+ * src/raytrace.zig:11-106, 117-255).  The per-ray arithmetic lives in vr_trace_core.h.
  *
- * Follows renderImage / traceRay (src/raytrace.zig:11-106, 117-255); the per-ray arithmetic lives
- * in vr_trace_core.h.  The path is latency/VALU bound pointer chasing over 4-byte nodes: there is
- * no matrix work, so no MFMA.
+ * The path is VALU/latency-bound pointer chasing over 4-byte nodes with no matrix work (no MFMA).
+ * Two families of kernels:
+ *
+ *  per-pixel   one thread per pixel and iso value, 8x8-pixel tiles per wave64.  The literal
+ *              root-restart loop (from global memory, or with the top tree levels in LDS) is the
+ *              on-GPU anchor; a resume variant runs the same lane code as the pipeline below.
+ *
+ *  pipeline    (default) what makes the sweep fast:
+ *    1. classify + compact: the entry test of traceRay (src/raytrace.zig:122-156) does not depend on
+ *       the iso value, so it runs once per view; rays that enter the volume are written, in tile
+ *       order, to a dense list (direction, entry t, pixel).
+ *    2. frames are zero-filled (OOB and miss pixels are black, src/raytrace.zig:54,67).
+ *    3. persistent trace kernel: waves pull rays of one iso value at a time from that iso's queue
+ *       and REFILL idle lanes as their rays finish, so lanes stay busy although ray lengths vary by
+ *       three orders of magnitude.  Traversal resumes from the lowest valid ancestor after each
+ *       MOVE (path stack in LDS) instead of restarting at the root.  Only hit pixels are stored.
  */
 #include "vr_internal.h"
 
 namespace {
 
-constexpr uint32_t kTileW = 8, kTileH = 8;   /* pixels per wave                       */
+constexpr uint32_t kTileW = 8, kTileH = 8;     /* pixels per wave                         */
 constexpr uint32_t kBlockW = 16, kBlockH = 16; /* pixels per 256-thread block (2x2 waves) */
-constexpr uint32_t kTopNodes = 4095;         /* heap levels 0..11, 16 KiB of LDS      */
+constexpr uint32_t kTopNodes = 4095;           /* heap levels 0..11, 16 KiB of LDS        */
+constexpr uint32_t kRefillMin = 16;            /* refill a wave once this many lanes idle */
 
 struct GlobalFetch {
     const uint32_t *nodes;
@@ -28,11 +42,12 @@ struct TopLdsFetch {
     }
 };
 
-/* one 16-bit record per level, one column per lane: [level][lane] */
+/* path stack: one 32-bit word per level, one column per thread of the block: [level][thread] */
 struct LdsStack {
-    uint16_t *col;
-    __device__ __forceinline__ void push(uint32_t level, uint32_t rec) { col[level * 64u] = (uint16_t)rec; }
-    __device__ __forceinline__ uint32_t pop(uint32_t level) const { return col[level * 64u]; }
+    uint32_t *col;
+    uint32_t stride;
+    __device__ __forceinline__ void push(uint32_t level, uint32_t word) { col[level * stride] = word; }
+    __device__ __forceinline__ uint32_t pop(uint32_t level) const { return col[level * stride]; }
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
@@ -42,13 +57,27 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
     return x;
 }
 
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+__device__ __forceinline__ void add_stat(uint64_t *p, unsigned long long v)
+{
+    if (v) atomicAdd((unsigned long long *)p, v);
+}
+
+/* ------------------------------------------------------------------ per-pixel kernels ---- */
+
 template <int VARIANT>
 __global__ __launch_bounds__(256) void vr_k_render(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t iso_begin,
                                                    uint32_t row_begin, uint32_t n_rows, uint8_t *__restrict__ rgb,
                                                    vr_render_stats *__restrict__ stats, VrTapsK taps)
 {
     __shared__ uint32_t s_top[VARIANT == VR_KERNEL_RESTART_LDS ? kTopNodes : 1];
-    __shared__ uint16_t s_stack[VARIANT == VR_KERNEL_RESUME ? 4 * (VR_MAX_DEPTH + 1) * 64 : 1];
+    extern __shared__ uint32_t s_dyn[]; /* resume variant: path stack, [levels][256] */
 
     const uint32_t tiles_x = (v.width + kBlockW - 1) / kBlockW;
     const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
@@ -73,7 +102,7 @@ __global__ __launch_bounds__(256) void vr_k_render(VrViewK v, const uint32_t *__
         } else if (VARIANT == VR_KERNEL_RESTART_LDS) {
             h = vr_trace_restart(v, ray, iso, TopLdsFetch{ nodes, s_top });
         } else {
-            LdsStack st{ s_stack + wave * ((VR_MAX_DEPTH + 1) * 64) + lane };
+            LdsStack st{ s_dyn + threadIdx.x, 256u };
             h = vr_trace_resume(v, ray, iso, GlobalFetch{ nodes }, st);
         }
         const uint64_t pix = ((uint64_t)blockIdx.y * n_rows + yr) * v.width + xi;
@@ -97,40 +126,326 @@ __global__ __launch_bounds__(256) void vr_k_render(VrViewK v, const uint32_t *__
         const uint32_t c_err = wave_sum(valid ? h.error : 0u);
         if (lane == 0) {
             vr_render_stats *s = stats + blockIdx.y;
-            if (c_checked) atomicAdd((unsigned long long *)&s->nodes_checked, (unsigned long long)c_checked);
-            if (c_hit) atomicAdd((unsigned long long *)&s->hit_count, (unsigned long long)c_hit);
-            if (c_miss) atomicAdd((unsigned long long *)&s->miss_count, (unsigned long long)c_miss);
-            if (c_oob) atomicAdd((unsigned long long *)&s->oob_count, (unsigned long long)c_oob);
-            if (c_esc) atomicAdd((unsigned long long *)&s->escape_help_events, (unsigned long long)c_esc);
-            if (c_moves) atomicAdd((unsigned long long *)&s->moves, (unsigned long long)c_moves);
-            if (c_err) atomicAdd((unsigned long long *)&s->errors, (unsigned long long)c_err);
+            add_stat(&s->nodes_checked, c_checked);
+            add_stat(&s->hit_count, c_hit);
+            add_stat(&s->miss_count, c_miss);
+            add_stat(&s->oob_count, c_oob);
+            add_stat(&s->escape_help_events, c_esc);
+            add_stat(&s->moves, c_moves);
+            add_stat(&s->errors, c_err);
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- pipeline: pre-pass ---- */
+
+/* tile t covers pixels [8*(t % tiles_x), +8) x [8*(t / tiles_x), +8) of the rendered row range */
+__device__ __forceinline__ bool tile_ray(const VrViewK &v, uint32_t tile, uint32_t lane, uint32_t tiles_x,
+                                         uint32_t row_begin, uint32_t n_rows, VrRay &ray, uint32_t &pix)
+{
+    const uint32_t xi = (tile % tiles_x) * kTileW + (lane & 7u);
+    const uint32_t yr = (tile / tiles_x) * kTileH + (lane >> 3);
+    pix = yr * v.width + xi;
+    if (xi >= v.width || yr >= n_rows) return false;
+    ray = vr_make_ray(v, xi, yr + row_begin);
+    return !ray.oob;
+}
+
+/* 1a: number of rays per tile that enter the root box */
+__global__ __launch_bounds__(256) void vr_k_count(VrViewK v, uint32_t row_begin, uint32_t n_rows, uint32_t n_tiles,
+                                                  uint32_t *__restrict__ tile_count)
+{
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (tile >= n_tiles) return;
+    const uint32_t tiles_x = (v.width + kTileW - 1) / kTileW;
+    VrRay ray;
+    uint32_t pix;
+    const bool active = tile_ray(v, tile, lane, tiles_x, row_begin, n_rows, ray, pix);
+    const unsigned long long m = __ballot(active);
+    if (lane == 0) tile_count[tile] = (uint32_t)__popcll(m);
+}
+
+/* 1b: exclusive scan of the tile counts in place, by one block; writes the total */
+__global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ tile_count, uint32_t n_tiles,
+                                                  uint32_t *__restrict__ n_active_out)
+{
+    __shared__ uint32_t s_part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_tiles + 1023u) / 1024u;
+    const uint32_t b = tid * per, e = b + per < n_tiles ? b + per : n_tiles;
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; i++) sum += tile_count[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) { /* Hillis-Steele inclusive scan of the partials */
+        uint32_t x = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += x;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (uint32_t i = b; i < e; i++) {
+        const uint32_t c = tile_count[i];
+        tile_count[i] = run;
+        run += c;
+    }
+    if (tid == 1023u) *n_active_out = s_part[1023];
+}
+
+/* 1c: dense ray list in tile order: (dx, dy, dz, entry t) and the pixel index inside one frame */
+__global__ __launch_bounds__(256) void vr_k_compact(VrViewK v, uint32_t row_begin, uint32_t n_rows, uint32_t n_tiles,
+                                                    const uint32_t *__restrict__ tile_off, float4 *__restrict__ ray_dt,
+                                                    uint32_t *__restrict__ ray_pix)
+{
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (tile >= n_tiles) return;
+    const uint32_t tiles_x = (v.width + kTileW - 1) / kTileW;
+    VrRay ray;
+    uint32_t pix;
+    const bool active = tile_ray(v, tile, lane, tiles_x, row_begin, n_rows, ray, pix);
+    const unsigned long long m = __ballot(active);
+    if (active) {
+        const uint32_t slot = tile_off[tile] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        ray_dt[slot] = make_float4(ray.dx, ray.dy, ray.dz, ray.t);
+        ray_pix[slot] = pix;
+    }
+}
+
+/* every pixel that never enters the volume is OOB in every frame: per-frame count, and tap defaults */
+__global__ void vr_k_oob_stats(vr_render_stats *__restrict__ stats, uint32_t iso_count, uint64_t frame_pixels,
+                               const uint32_t *__restrict__ n_active)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < iso_count) stats[k].oob_count = frame_pixels - *n_active;
+}
+
+__global__ void vr_k_tap_defaults(VrTapsK taps, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (taps.cell_flag) taps.cell_flag[i] = VR_FLAG_OOB << 24;
+        if (taps.t) taps.t[i] = 0.0f;
+        if (taps.checked) taps.checked[i] = 0u;
+        if (taps.node) taps.node[i] = 0u;
+    }
+}
+
+/* --------------------------------------------------------- pipeline: persistent trace ---- */
+
+template <bool TAPS>
+__global__ __launch_bounds__(256) void vr_k_trace(VrViewK v, const uint32_t *__restrict__ nodes,
+                                                  const float4 *__restrict__ ray_dt, const uint32_t *__restrict__ ray_pix,
+                                                  const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ heads,
+                                                  uint32_t iso_begin, uint32_t iso_count, uint64_t frame_pixels,
+                                                  uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats, VrTapsK taps)
+{
+    extern __shared__ uint32_t s_dyn[]; /* path stack, [levels][256] */
+    LdsStack stack{ s_dyn + threadIdx.x, 256u };
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_active = *n_active_ptr;
+    const uint32_t n_waves = gridDim.x * 4u, gw = blockIdx.x * 4u + (threadIdx.x >> 6);
+    /* spread the waves over the iso queues; each wave then walks all queues cyclically, so waves that
+     * run out of work on a cheap iso value move on to help with the expensive ones */
+    const uint32_t k0 = (uint32_t)(((uint64_t)gw * iso_count) / n_waves);
+
+    for (uint32_t visit = 0; visit < iso_count; visit++) {
+        uint32_t k = k0 + visit;
+        if (k >= iso_count) k -= iso_count;
+        const uint32_t iso = iso_begin + k;
+        uint8_t *frame = rgb + (uint64_t)k * frame_pixels * 3u;
+        const uint64_t tap_base = (uint64_t)k * frame_pixels;
+
+        VrLane L;
+        uint32_t pix = 0;
+        bool alive = false, exhausted = false;
+        unsigned long long a_checked = 0;
+        uint32_t a_hit = 0, a_miss = 0, a_moves = 0, a_esc = 0, a_err = 0;
+
+        for (;;) {
+            /* ---- refill idle lanes from this iso value's queue ---- */
+            const unsigned long long idle = __ballot(!alive);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (!exhausted && n_idle >= kRefillMin) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&heads[k], n_idle);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!alive && mine < n_active) {
+                    const float4 r = ray_dt[mine];
+                    pix = ray_pix[mine];
+                    vr_lane_begin(L, v, r.x, r.y, r.z, r.w);
+                    alive = true;
+                }
+                exhausted = base + n_idle >= n_active;
+            }
+            if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
+
+            if (alive) {
+                /* ---- descend while the node's density range holds the iso value ---- */
+                uint32_t n;
+                bool holds;
+                for (;;) {
+                    n = nodes[L.idx];
+                    L.checked++;
+                    holds = vr_node_holds(n, iso);
+                    if (!holds || (n & VR_N_LEAF)) break;
+                    vr_lane_zoom(L, n, stack);
+                }
+                if (holds) { /* hit: shade and store (src/raytrace.zig:56-61) */
+                    const uint8_t g = vr_shade(L.t);
+                    frame[(uint64_t)pix * 3u + 0u] = g;
+                    frame[(uint64_t)pix * 3u + 1u] = g;
+                    frame[(uint64_t)pix * 3u + 2u] = g;
+                    a_hit++;
+                    alive = false;
+                    if (TAPS) {
+                        if (taps.cell_flag) taps.cell_flag[tap_base + pix] = vr_unpack_cell(L.cell) | (VR_FLAG_HIT << 24);
+                        if (taps.node) taps.node[tap_base + pix] = L.idx;
+                    }
+                } else {
+                    a_moves++;
+                    bool in_root = vr_lane_move(L, v, a_esc);
+                    if (L.checked > VR_MAX_CHECKED) { in_root = false; a_err++; }
+                    if (in_root) {
+                        vr_lane_pop(L, stack);
+                    } else { /* left the volume: a miss, the pixel stays black (src/raytrace.zig:66-68) */
+                        a_miss++;
+                        alive = false;
+                        if (TAPS) {
+                            if (taps.cell_flag) taps.cell_flag[tap_base + pix] = VR_FLAG_MISS << 24;
+                            if (taps.node) taps.node[tap_base + pix] = 0u;
+                        }
+                    }
+                }
+                if (!alive) {
+                    a_checked += L.checked;
+                    if (TAPS) {
+                        if (taps.t) taps.t[tap_base + pix] = L.t;
+                        if (taps.checked) taps.checked[tap_base + pix] = L.checked;
+                    }
+                }
+            }
+        }
+
+        /* ---- per-iso counters: one atomic per wave and counter ---- */
+        if (stats) {
+            const unsigned long long c_checked = wave_sum64(a_checked);
+            const uint32_t c_hit = wave_sum(a_hit), c_miss = wave_sum(a_miss), c_moves = wave_sum(a_moves);
+            const uint32_t c_esc = wave_sum(a_esc), c_err = wave_sum(a_err);
+            if (lane == 0) {
+                vr_render_stats *s = stats + k;
+                add_stat(&s->nodes_checked, c_checked);
+                add_stat(&s->hit_count, c_hit);
+                add_stat(&s->miss_count, c_miss);
+                add_stat(&s->escape_help_events, c_esc);
+                add_stat(&s->moves, c_moves);
+                add_stat(&s->errors, c_err);
+            }
         }
     }
 }
 
 } // namespace
 
-hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes,
-                            uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end,
-                            uint8_t *d_rgb, vr_render_stats *d_stats, const VrTapsK &taps)
+size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count)
+{
+    const size_t n_pix = (size_t)width * n_rows;
+    const size_t n_tiles = (size_t)((width + kTileW - 1) / kTileW) * ((n_rows + kTileH - 1) / kTileH);
+    size_t bytes = 0;
+    bytes += (n_pix * sizeof(float4) + 255) & ~(size_t)255; /* ray_dt     */
+    bytes += (n_pix * sizeof(uint32_t) + 255) & ~(size_t)255; /* ray_pix    */
+    bytes += (n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255; /* tile count / offset */
+    bytes += 256;                                               /* n_active   */
+    bytes += ((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255; /* queue heads */
+    return bytes;
+}
+
+hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_raw,
+                            const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
+                            uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
+                            const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     const uint32_t n_rows = row_end - row_begin;
-    const uint32_t tiles_x = (view.width + kBlockW - 1) / kBlockW;
-    const uint32_t tiles_y = (n_rows + kBlockH - 1) / kBlockH;
-    dim3 grid(tiles_x * tiles_y, iso_count, 1), block(256, 1, 1);
-    switch (variant) {
-    case VR_KERNEL_RESTART_GLOBAL:
-        hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESTART_GLOBAL>, grid, block, 0, stream, view, d_nodes, iso_begin,
-                           row_begin, n_rows, d_rgb, d_stats, taps);
-        break;
-    case VR_KERNEL_RESTART_LDS:
-        hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESTART_LDS>, grid, block, 0, stream, view, d_nodes, iso_begin,
-                           row_begin, n_rows, d_rgb, d_stats, taps);
-        break;
-    default:
-        hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESUME>, grid, block, 0, stream, view, d_nodes, iso_begin, row_begin,
-                           n_rows, d_rgb, d_stats, taps);
-        break;
+    const uint32_t stack_levels = max_depth > 0 ? max_depth : 1u;
+    const size_t stack_bytes = (size_t)stack_levels * 256u * sizeof(uint32_t);
+    hipError_t e;
+
+    if (variant != VR_KERNEL_PIPELINE) {
+        const uint32_t tiles_x = (view.width + kBlockW - 1) / kBlockW;
+        const uint32_t tiles_y = (n_rows + kBlockH - 1) / kBlockH;
+        dim3 grid(tiles_x * tiles_y, iso_count, 1), block(256, 1, 1);
+        if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
+        switch (variant) {
+        case VR_KERNEL_RESTART_GLOBAL:
+            hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESTART_GLOBAL>, grid, block, 0, stream, view, d_nodes_raw, iso_begin,
+                               row_begin, n_rows, d_rgb, d_stats, taps);
+            break;
+        case VR_KERNEL_RESTART_LDS:
+            hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESTART_LDS>, grid, block, 0, stream, view, d_nodes_raw, iso_begin,
+                               row_begin, n_rows, d_rgb, d_stats, taps);
+            break;
+        default:
+            hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESUME>, grid, block, stack_bytes, stream, view, d_nodes_prepared,
+                               iso_begin, row_begin, n_rows, d_rgb, d_stats, taps);
+            break;
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+        return hipSuccess;
     }
-    return hipGetLastError();
+
+    /* ---- pipeline ---- */
+    const size_t n_pix = (size_t)view.width * n_rows;
+    const uint32_t tiles_x = (view.width + kTileW - 1) / kTileW, tiles_y = (n_rows + kTileH - 1) / kTileH;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    char *w = (char *)workspace;
+    float4 *ray_dt = (float4 *)w;
+    w += (n_pix * sizeof(float4) + 255) & ~(size_t)255;
+    uint32_t *ray_pix = (uint32_t *)w;
+    w += (n_pix * sizeof(uint32_t) + 255) & ~(size_t)255;
+    uint32_t *tile_cnt = (uint32_t *)w;
+    w += ((size_t)n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255;
+    uint32_t *n_active = (uint32_t *)w;
+    w += 256;
+    uint32_t *heads = (uint32_t *)w;
+
+    const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
+    if ((e = hipMemsetAsync(heads, 0, (size_t)iso_count * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
+    const uint32_t tile_blocks = (n_tiles + 3u) / 4u;
+    hipLaunchKernelGGL(vr_k_count, dim3(tile_blocks), dim3(256), 0, stream, view, row_begin, n_rows, n_tiles, tile_cnt);
+    hipLaunchKernelGGL(vr_k_scan, dim3(1), dim3(1024), 0, stream, tile_cnt, n_tiles, n_active);
+    hipLaunchKernelGGL(vr_k_compact, dim3(tile_blocks), dim3(256), 0, stream, view, row_begin, n_rows, n_tiles, tile_cnt,
+                       ray_dt, ray_pix);
+    if (d_stats)
+        hipLaunchKernelGGL(vr_k_oob_stats, dim3((iso_count + 255u) / 256u), dim3(256), 0, stream, d_stats, iso_count,
+                           (uint64_t)n_pix, n_active);
+    if (any_tap) hipLaunchKernelGGL(vr_k_tap_defaults, dim3(2048), dim3(256), 0, stream, taps, (uint64_t)n_pix * iso_count);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+
+    /* persistent grid: as many blocks as stay resident (8 blocks of 4 waves fill a CU's 32 wave slots) */
+    static size_t occ_key[2] = { ~(size_t)0, ~(size_t)0 };
+    static int occ_val[2] = { 0, 0 };
+    const int ti = any_tap ? 1 : 0;
+    if (occ_key[ti] != stack_bytes) {
+        int occ = 0;
+        if (any_tap)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vr_k_trace<true>, 256, stack_bytes);
+        else
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vr_k_trace<false>, 256, stack_bytes);
+        if (e != hipSuccess) return e;
+        occ_val[ti] = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
+        occ_key[ti] = stack_bytes;
+    }
+    const uint32_t blocks = (uint32_t)n_cus * (uint32_t)occ_val[ti];
+
+    if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
+    if (any_tap)
+        hipLaunchKernelGGL(vr_k_trace<true>, dim3(blocks), dim3(256), stack_bytes, stream, view, d_nodes_prepared, ray_dt,
+                           ray_pix, n_active, heads, iso_begin, iso_count, (uint64_t)n_pix, d_rgb, d_stats, taps);
+    else
+        hipLaunchKernelGGL(vr_k_trace<false>, dim3(blocks), dim3(256), stack_bytes, stream, view, d_nodes_prepared, ray_dt,
+                           ray_pix, n_active, heads, iso_begin, iso_count, (uint64_t)n_pix, d_rgb, d_stats, taps);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+    return hipSuccess;
 }

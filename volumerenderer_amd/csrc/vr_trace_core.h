@@ -28,7 +28,7 @@
 #endif
 
 #define VR_MAX_DEPTH 31 /* deepest node level a heap index below 2^32 can address */
-#define VR_MAX_MOVES (1u << 20) /* safety valve: no ray through a <=256^3 volume skips this many nodes */
+#define VR_MAX_MOVES (1u << 20) /* safety valve of the literal loop: no ray through a <=256^3 volume skips this many nodes */
 
 /* Boxes and cells are kept as three 8-bit values in 10-bit fields (bits 0-7, 10-17, 20-27) so
  * that one 32-bit subtract compares all three axes at once: bit 8 of every field is a guard. */
@@ -203,90 +203,136 @@ VR_HD VrHit vr_trace_restart(const VrViewK &v, const VrRay &ray, uint32_t iso, N
  * After a MOVE the reference walks down again from the root.  Every node on the path to the node
  * just skipped passed its iso test, and the child choice at each level is a pure function of the
  * point, so the new walk follows the old path down to the lowest ancestor whose box still holds
- * the new point -- node for node.  This variant therefore keeps the path (one small record per
- * level), pops ancestors until the box holds the new point, credits the `depth` node checks the
- * reference would have spent getting there, and carries on from that ancestor.  Hit cell, t,
- * flags and the reference-defined checked count are identical; far fewer nodes are read.
+ * the new point -- node for node.  This variant therefore keeps the path (one word per level),
+ * pops ancestors until the box holds the new point, credits the `depth` node checks the reference
+ * would have spent getting there, and carries on from that ancestor.  Hit cell, t, flags and the
+ * reference-defined checked count are identical; far fewer nodes are read.
  *
- * Stack record per level: axis | old_bound << 2 (the bound of the parent box that the zoom
- * replaced).  `Stack` provides push(level, rec) / pop(level).
+ * It walks the PREPARED node array (vr_host_prepare_kdt): the reference's SlimNode word with the
+ * axis replaced by the field shift (axis * 10) and a leaf flag, produced by a validating walk that
+ * guarantees every reachable inner node splits strictly inside its box.  That guarantee is what
+ * lets the loops below run without index, axis or depth checks.
+ *
+ *   bits 0-7 min | 8-15 max | 16-23 partition | 24-28 shift | 31 leaf
+ *
+ * Stack word per level: the packed bound word (lo or hi) the zoom replaced.  `Stack` provides
+ * push(level, word) / pop(level).
  * ---------------------------------------------------------------------------------------- */
+#define VR_N_LEAF 0x80000000u
+#define VR_MAX_CHECKED (1u << 27) /* safety valve per ray; a 256^3 volume stays far below it */
+
+struct VrLane {
+    float dx, dy, dz, t;
+    uint32_t cell;    /* packed floor(point), valid while the point is inside the root box */
+    uint32_t lo, hi;  /* packed box of the current node */
+    uint32_t idx, depth;
+    uint32_t posmask; /* 0x3ff in the field of every axis the ray travels in the + direction */
+    uint32_t checked; /* reference-defined node checks of this ray */
+};
+
+VR_HD void vr_lane_begin(VrLane &L, const VrViewK &v, float dx, float dy, float dz, float t)
+{
+    L.dx = dx; L.dy = dy; L.dz = dz; L.t = t;
+    /* inside the root box every coordinate is >= 0, so trunc == floor */
+    L.cell = vr_pack10((uint32_t)(v.ox + dx * t), (uint32_t)(v.oy + dy * t), (uint32_t)(v.oz + dz * t));
+    L.lo = 0; L.hi = v.root_hi;
+    L.idx = 0; L.depth = 0; L.checked = 0;
+    L.posmask = (dx >= 0.0f ? 0x3ffu : 0u) | (dy >= 0.0f ? (0x3ffu << 10) : 0u) | (dz >= 0.0f ? (0x3ffu << 20) : 0u);
+}
+
+/* Range.containsInclusive on the node's density range, src/geo.zig:196-198 */
+VR_HD bool vr_node_holds(uint32_t n, uint32_t iso) { return (n & 0xffu) <= iso && iso <= ((n >> 8) & 0xffu); }
+
+/* SpaceTracker.zoom (src/SlimKDT.zig:90-103) on an inner node whose range holds the iso value */
+template <class Stack>
+VR_HD void vr_lane_zoom(VrLane &L, uint32_t n, Stack &stack)
+{
+    const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
+    const bool left = ((L.cell >> sh) & 0xffu) < part;
+    uint32_t side = left ? L.hi : L.lo;
+    stack.push(L.depth, side);
+    side = (side & ~(0xffu << sh)) | (part << sh); /* partition is strictly inside the box: min/max of geo.zig:256-275 pick it */
+    L.hi = left ? side : L.hi;
+    L.lo = left ? L.lo : side;
+    L.idx = 2u * L.idx + (left ? 1u : 2u);
+    L.depth++;
+}
+
+/* MOVE (src/raytrace.zig:199-205) + escape help (:233-242).  Returns false when the new point is
+ * outside the root box (the restarted loop would fail its condition there: a miss). */
+VR_HD bool vr_lane_move(VrLane &L, const VrViewK &v, uint32_t &escapes)
+{
+    const uint32_t ex = (L.hi & L.posmask) | (L.lo & ~L.posmask); /* exit plane per axis: max if d >= 0 else min */
+    float t = INFINITY;
+    t = fminf(t, vr_plane_t((float)(ex & 0xffu), v.ox, L.dx));
+    t = fminf(t, vr_plane_t((float)((ex >> 10) & 0xffu), v.oy, L.dy));
+    t = fminf(t, vr_plane_t((float)((ex >> 20) & 0xffu), v.oz, L.dz));
+    t += 0.0001f;
+    float i = 0.0f;
+    bool in_root;
+    for (;;) {
+        const float px = v.ox + L.dx * t, py = v.oy + L.dy * t, pz = v.oz + L.dz * t;
+        in_root = vr_root_contains(v, px, py, pz);
+        if (!in_root) break; /* outside the root is outside every node box */
+        L.cell = vr_pack10((uint32_t)px, (uint32_t)py, (uint32_t)pz);
+        if (!vr_box_contains_cell(L.lo, L.hi, L.cell)) break;
+        t += 0.001f * i;
+        i += 1.0f;
+        escapes++;
+    }
+    L.t = t;
+    return in_root;
+}
+
+/* Pops ancestors until the box holds the new point, then credits the checks the reference spends
+ * walking root .. parent(ancestor) again.  Precondition: the point is inside the root box and
+ * outside the current box. */
+template <class Stack>
+VR_HD void vr_lane_pop(VrLane &L, Stack &stack)
+{
+    while (L.depth > 0) {
+        L.depth--;
+        const uint32_t word = stack.pop(L.depth);
+        if (L.idx & 1u) L.hi = word; else L.lo = word; /* odd index = left child: the zoom had cut hi */
+        L.idx = (L.idx - 1u) >> 1;
+        if (vr_box_contains_cell(L.lo, L.hi, L.cell)) break;
+    }
+    L.checked += L.depth;
+}
+
+VR_HD uint32_t vr_unpack_cell(uint32_t c10) { return (c10 & 0xffu) | (((c10 >> 10) & 0xffu) << 8) | (((c10 >> 20) & 0xffu) << 16); }
+
+/* one ray from entry to hit or miss; `fetch` reads the PREPARED node array */
 template <class NodeFetch, class Stack>
 VR_HD VrHit vr_trace_resume(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Stack &stack)
 {
     VrHit h;
     h.t = 0.0f; h.flag = 2u; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
     if (ray.oob) return h;
-    float t = ray.t;
-    uint32_t lo = 0, hi = v.root_hi;
-    uint32_t idx = 0, depth = 0;
-    /* inside the root box every coordinate is >= 0, so trunc == floor */
-    uint32_t cell = vr_pack10((uint32_t)(v.ox + ray.dx * t), (uint32_t)(v.oy + ray.dy * t), (uint32_t)(v.oz + ray.dz * t));
-    const bool xpos = ray.dx >= 0.0f, ypos = ray.dy >= 0.0f, zpos = ray.dz >= 0.0f;
-    for (;;) {
-        /* ---- descend while the node's density range holds the iso value ---- */
-        bool done = false;
-        for (;;) {
-            h.checked++;
-            if (idx >= v.n_slots) { h.error = 1; done = true; break; }
-            uint32_t n = fetch(idx);
-            uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
-            if (!(mn <= iso && iso <= mx)) break; /* -> MOVE */
-            if (hi - lo == VR_F_ONES) {           /* all three extents are 1: a leaf cell */
-                h.t = t; h.flag = 1u; h.node = idx;
-                h.cell = (cell & 0xffu) | (((cell >> 10) & 0xffu) << 8) | (((cell >> 20) & 0xffu) << 16);
-                return h;
-            }
-            uint32_t axis = (n >> 24) & 3u, part = (n >> 16) & 0xffu;
-            if (axis > 2u || depth >= VR_MAX_DEPTH) { h.error = 1; done = true; break; }
-            uint32_t sh = axis * 10u;
-            bool left = ((cell >> sh) & 0xffu) < part;
-            uint32_t side = left ? hi : lo;
-            uint32_t old = (side >> sh) & 0xffu;
-            uint32_t nb = left ? (old < part ? old : part) : (old > part ? old : part);
-            side = (side & ~(0xffu << sh)) | (nb << sh);
-            if (left) hi = side; else lo = side;
-            stack.push(depth, axis | (old << 2));
-            idx = 2u * idx + (left ? 1u : 2u);
-            depth++;
-        }
-        if (done) break;
-        /* ---- MOVE: leave the node box through the nearest exit plane (:199-205) ---- */
-        t = INFINITY;
-        t = fminf(t, vr_plane_t((float)vr_field(xpos ? hi : lo, 0), v.ox, ray.dx));
-        t = fminf(t, vr_plane_t((float)vr_field(ypos ? hi : lo, 1), v.oy, ray.dy));
-        t = fminf(t, vr_plane_t((float)vr_field(zpos ? hi : lo, 2), v.oz, ray.dz));
-        t += 0.0001f;
-        if (++h.moves > VR_MAX_MOVES) { h.error = 1; break; }
-        float px, py, pz;
-        bool in_root;
-        float i = 0.0f;
-        for (;;) { /* escape help (:233-242): nudge until the point is outside the skipped box */
-            px = v.ox + ray.dx * t; py = v.oy + ray.dy * t; pz = v.oz + ray.dz * t;
-            in_root = vr_root_contains(v, px, py, pz);
-            if (!in_root) break; /* outside the root is outside every node box */
-            cell = vr_pack10((uint32_t)px, (uint32_t)py, (uint32_t)pz);
-            if (!vr_box_contains_cell(lo, hi, cell)) break;
-            t += 0.001f * i;
-            i += 1.0f;
-            h.escapes++;
-        }
-        if (!in_root) break; /* the restarted loop would fail its condition at the root: a miss */
-        /* ---- pop ancestors until the box holds the new point ---- */
-        while (depth > 0) {
-            uint32_t rec = stack.pop(depth - 1);
-            uint32_t sh = (rec & 3u) * 10u, old = rec >> 2;
-            if (idx & 1u) hi = (hi & ~(0xffu << sh)) | (old << sh); /* left child: the zoom had cut hi */
-            else lo = (lo & ~(0xffu << sh)) | (old << sh);
-            idx = (idx - 1u) >> 1;
-            depth--;
-            if (vr_box_contains_cell(lo, hi, cell)) break;
-        }
-        /* the reference re-checks root .. parent(this node) on its way back down */
-        h.checked += depth;
-    }
-    h.t = t;
+    VrLane L;
+    vr_lane_begin(L, v, ray.dx, ray.dy, ray.dz, ray.t);
     h.flag = 0u;
+    for (;;) {
+        uint32_t n;
+        bool holds;
+        for (;;) { /* descend while the node's density range holds the iso value */
+            n = fetch(L.idx);
+            L.checked++;
+            holds = vr_node_holds(n, iso);
+            if (!holds || (n & VR_N_LEAF)) break;
+            vr_lane_zoom(L, n, stack);
+        }
+        if (holds) { /* a leaf cell whose range holds the iso value: the hit (src/raytrace.zig:178-187) */
+            h.flag = 1u; h.node = L.idx; h.cell = vr_unpack_cell(L.cell);
+            break;
+        }
+        h.moves++;
+        if (L.checked > VR_MAX_CHECKED) { h.error = 1; break; }
+        if (!vr_lane_move(L, v, h.escapes)) break;
+        vr_lane_pop(L, stack);
+    }
+    h.t = L.t;
+    h.checked = L.checked;
     return h;
 }
 
