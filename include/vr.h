@@ -119,15 +119,23 @@ int vr_host_build_kdt(const uint8_t *vox, const uint32_t res[3], int heuristic, 
                       uint32_t **nodes_out, uint64_t *n_slots_out, uint8_t root_dim_out[3],
                       vr_build_stats *stats_out);
 
-/* The flattening step in front of the GPU: walks the heap-indexed SlimNode array from the root with
+/* The flattening step in front of the GPU.  Walks the heap-indexed SlimNode array from the root with
  * the boxes SpaceTracker would hold (src/SlimKDT.zig:55-103), checks that every reachable node lies
  * inside the array and that every inner node's partition is strictly inside its box (what the
  * reference's builder always produces; anything else never reaches a leaf in the reference's zoom
- * either), and writes the word the kernels read: bits 0-23 unchanged (min, max, partition), bits
- * 24-28 = axis * 10, bit 31 = leaf (box of one cell).  prepared_out has n_slots words.  Returns
- * VR_ETREE for a malformed tree.  max_depth_out = deepest level (root = 0). */
+ * either: VR_ETREE), and writes the array the kernels walk:
+ *   word    bits 0-23 unchanged (min, max, partition), bits 24-28 = axis * 10, bit 31 = leaf
+ *   layout  5-level subtrees ("treelets", 31 nodes) stored in one 128-byte line each, so a descent
+ *           touches one cache line per five levels instead of one per level.  With g = heap index
+ *           + 1 at depth d = 5q + r: word address = 32 * ((g >> r) - C(q)) + ((1 << r) | (g & ((1 <<
+ *           r) - 1))), C(q) = (30 * 32^q + 1) / 31.  Unoccupied words are 0.
+ * Call once with prepared_out = NULL to validate and learn max_depth (root = 0), allocate
+ * vr_prepared_words(max_depth) words, call again to fill them.  Trees deeper than 29 levels give
+ * VR_ETOODEEP. */
+uint64_t vr_prepared_words(uint32_t max_depth);
 int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3],
-                        uint32_t *prepared_out, uint32_t *max_depth_out, uint64_t *n_nodes_out);
+                        uint32_t *prepared_out, uint64_t prepared_words, uint32_t *max_depth_out,
+                        uint64_t *n_nodes_out);
 
 /* Camera of the reference driver (src/main.zig:31-43): forw = norm(f32(res/2) - pos),
  * up = (forw x (0,1,0)) x forw (not normalised). */

@@ -20,8 +20,8 @@ struct HostStack {
 };
 } // namespace
 
-/* variant 1 walks the reference's SlimNode array; any other variant walks the PREPARED array
- * (vr_host_prepare_kdt of the product library) with the resume traversal */
+/* variant 1 walks the reference's SlimNode array with the literal restart loop; any other variant walks
+ * the PREPARED array (vr_host_prepare_kdt of the product library) with the resume traversal */
 extern "C" int vr_emu_render(int variant, const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3],
                              const float src[3], const float forw[3], const float up[3], uint32_t width,
                              uint32_t height, float viewport_width, uint32_t iso, uint8_t *rgb, uint32_t *cell_flag,

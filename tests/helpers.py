@@ -4,19 +4,34 @@ import numpy as np
 
 
 def prepare_nodes(nodes, rd):
-    """vr_host_prepare_kdt of the product library (host-only): validated, flattened node words."""
+    """vr_host_prepare_kdt of the product library (host-only): validated node words in treelet layout."""
     from volumerenderer_amd import capi
+    L = capi.lib()
     nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
-    out = np.zeros_like(nodes)
+    rd3 = (C.c_uint8 * 3)(*[int(x) for x in rd])
     depth = C.c_uint32()
     count = C.c_uint64()
-    rc = capi.lib().vr_host_prepare_kdt(nodes.ctypes.data, len(nodes), (C.c_uint8 * 3)(*[int(x) for x in rd]),
-                                        out.ctypes.data, C.byref(depth), C.byref(count))
+    rc = L.vr_host_prepare_kdt(nodes.ctypes.data, len(nodes), rd3, None, 0, C.byref(depth), C.byref(count))
+    if rc != 0:
+        return rc, None, 0, 0
+    out = np.zeros(L.vr_prepared_words(depth.value), dtype=np.uint32)
+    rc = L.vr_host_prepare_kdt(nodes.ctypes.data, len(nodes), rd3, out.ctypes.data, len(out), C.byref(depth),
+                               C.byref(count))
     return rc, out, depth.value, count.value
+
+
+def treelet_address(g, d):
+    """word address of 1-based heap position g at depth d in the prepared (treelet) layout"""
+    q, r = divmod(d, 5)
+    c = 1
+    for _ in range(q):
+        c = 32 * c - 1
+    return 32 * ((g >> r) - c) + ((1 << r) | (g & ((1 << r) - 1)))
 
 
 def emu_render(L, variant, nodes, rd, pos, f, u, w, h, vp, iso):
     """Runs the kernels' lane code on the CPU (tests/emu/vr_emu.cpp)."""
+    n_slots = len(nodes)
     if variant != 1:
         rc, nodes, _, _ = prepare_nodes(nodes, rd)
         assert rc == 0
@@ -28,7 +43,7 @@ def emu_render(L, variant, nodes, rd, pos, f, u, w, h, vp, iso):
     sums = np.zeros(7, np.uint64)
     f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
     nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
-    L.vr_emu_render(int(variant), C.c_void_p(nodes.ctypes.data), C.c_uint64(len(nodes)),
+    L.vr_emu_render(int(variant), C.c_void_p(nodes.ctypes.data), C.c_uint64(n_slots),
                     (C.c_uint8 * 3)(*[int(x) for x in rd]), f3(pos), f3(f), f3(u), C.c_uint32(w), C.c_uint32(h),
                     C.c_float(vp), C.c_uint32(iso), C.c_void_p(rgb.ctypes.data), C.c_void_p(cf.ctypes.data),
                     C.c_void_p(tt.ctypes.data), C.c_void_p(ck.ctypes.data), C.c_void_p(nd.ctypes.data),

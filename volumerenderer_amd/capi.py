@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvr_hip.so")
+LIB_PATH = os.environ.get("VR_LIB_PATH") or os.path.join(_HERE, "libvr_hip.so")  # VR_LIB_PATH: tuning builds
 
 VR_OK = 0
 VR_EARG, VR_ENOMEM, VR_ESTATE, VR_ETOODEEP, VR_EIO, VR_EFORMAT, VR_ENODEVICE = -1, -2, -3, -4, -5, -6, -7
@@ -35,7 +35,7 @@ HEURISTICS = {
 
 # every symbol include/vr.h declares; tests check that the library exports each of them
 EXPORTS = [
-    "vr_strerror", "vr_load_ucd", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_main_camera", "vr_free", "vr_ctx_create",
+    "vr_strerror", "vr_load_ucd", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_ctx_create",
     "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_render",
     "vr_render_sweep", "vr_render_device", "vr_sync", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
@@ -89,7 +89,9 @@ def lib():
     L.vr_load_ucd.argtypes = [C.c_char_p, C.POINTER(u8p), u32p]
     L.vr_host_build_kdt.argtypes = [vp, u32p, C.c_int, C.c_uint64, C.POINTER(u32p), C.POINTER(C.c_uint64), u8p,
                                     C.POINTER(BuildStats)]
-    L.vr_host_prepare_kdt.argtypes = [vp, C.c_uint64, u8p, vp, u32p, C.POINTER(C.c_uint64)]
+    L.vr_host_prepare_kdt.argtypes = [vp, C.c_uint64, u8p, vp, C.c_uint64, u32p, C.POINTER(C.c_uint64)]
+    L.vr_prepared_words.argtypes = [C.c_uint32]
+    L.vr_prepared_words.restype = C.c_uint64
     L.vr_main_camera.argtypes = [u32p, f32p, f32p, f32p]
     L.vr_main_camera.restype = None
     L.vr_free.argtypes = [vp]

@@ -157,19 +157,22 @@ int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint
     if (n_slots > ((uint64_t)1 << 32)) return VR_EARG; /* heap indices are u32, src/SlimKDT.zig:24-34 */
     if (root_dim[0] == 0 || root_dim[1] == 0 || root_dim[2] == 0) return VR_EARG;
     /* validate and flatten on the host before anything reaches the device */
-    uint32_t *prepared = (uint32_t *)std::malloc(n_slots * sizeof(uint32_t));
-    if (!prepared) return VR_ENOMEM;
     uint32_t max_depth = 0;
-    int rc = vr_host_prepare_kdt(nodes, n_slots, root_dim, prepared, &max_depth, nullptr);
+    int rc = vr_host_prepare_kdt(nodes, n_slots, root_dim, nullptr, 0, &max_depth, nullptr);
+    if (rc != VR_OK) return rc;
+    const uint64_t prep_words = vr_prepared_words(max_depth);
+    uint32_t *prepared = (uint32_t *)std::malloc(prep_words * sizeof(uint32_t));
+    if (!prepared) return VR_ENOMEM;
+    rc = vr_host_prepare_kdt(nodes, n_slots, root_dim, prepared, prep_words, &max_depth, nullptr);
     if (rc != VR_OK) { std::free(prepared); return rc; }
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
     if (e == hipSuccess && c->d_prepared) { e = hipFree(c->d_prepared); c->d_prepared = nullptr; }
     c->n_slots = 0;
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_nodes, n_slots * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_prepared, n_slots * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_prepared, prep_words * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(c->d_prepared, prepared, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_prepared, prepared, prep_words * sizeof(uint32_t), hipMemcpyHostToDevice);
     std::free(prepared);
     if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
     c->n_slots = n_slots;

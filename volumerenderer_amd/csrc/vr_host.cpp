@@ -24,6 +24,9 @@
 #include <vector>
 
 #include "../../include/vr.h"
+#include "vr_trace_core.h"
+
+#define VR_MAX_PREPARED_DEPTH 29u /* treelet word addresses stay below 2^32 up to this depth */
 
 namespace {
 
@@ -291,13 +294,18 @@ void vr_main_camera(const uint32_t res[3], const float pos[3], float forw_out[3]
     for (int k = 0; k < 3; k++) { forw_out[k] = f[k]; up_out[k] = u[k]; }
 }
 
-int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], uint32_t *prepared_out,
-                        uint32_t *max_depth_out, uint64_t *n_nodes_out)
+uint64_t vr_prepared_words(uint32_t max_depth)
 {
-    if (!nodes || !n_slots || !root_dim || !prepared_out) return VR_EARG;
+    return vr_treelet_count(max_depth) * VR_TREELET_WORDS;
+}
+
+int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], uint32_t *prepared_out,
+                        uint64_t prepared_words, uint32_t *max_depth_out, uint64_t *n_nodes_out)
+{
+    if (!nodes || !n_slots || !root_dim) return VR_EARG;
     if (n_slots > ((uint64_t)1 << 32)) return VR_EARG;
     if (root_dim[0] == 0 || root_dim[1] == 0 || root_dim[2] == 0) return VR_EARG;
-    std::memset(prepared_out, 0, n_slots * sizeof(uint32_t));
+    if (prepared_out) std::memset(prepared_out, 0, prepared_words * sizeof(uint32_t));
     struct Item { uint64_t idx; Box box; uint32_t depth; };
     std::vector<Item> todo;
     todo.reserve(128);
@@ -311,18 +319,27 @@ int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t r
         Item it = todo.back();
         todo.pop_back();
         if (it.idx >= n_slots) return VR_ETREE; /* a descent would read past the array */
+        if (it.depth > VR_MAX_PREPARED_DEPTH) return VR_ETOODEEP;
         const uint32_t n = nodes[it.idx];
         const uint32_t axis = (n >> 24) & 3u, part = (n >> 16) & 0xffu;
         count++;
         if (it.depth > max_depth) max_depth = it.depth;
-        if (it.box.size() == 1) { /* leaf cell: src/raytrace.zig:178 */
-            prepared_out[it.idx] = (n & 0x00ffffffu) | 0x80000000u;
-            continue;
+        uint32_t word;
+        const bool leaf = it.box.size() == 1; /* leaf cell: src/raytrace.zig:178 */
+        if (leaf) {
+            word = (n & 0x00ffffffu) | 0x80000000u;
+        } else {
+            /* an inner node must split strictly inside its box, else a child is empty and the other one
+             * repeats its parent: the reference's zoom (src/SlimKDT.zig:90-103) would never reach a leaf */
+            if (axis > 2u || part <= it.box.lo[axis] || part >= it.box.hi[axis]) return VR_ETREE;
+            word = (n & 0x00ffffffu) | ((axis * 10u) << 24);
         }
-        /* an inner node must split strictly inside its box, else a child is empty and the other one
-         * repeats its parent: the reference's zoom (src/SlimKDT.zig:90-103) would never reach a leaf */
-        if (axis > 2u || part <= it.box.lo[axis] || part >= it.box.hi[axis]) return VR_ETREE;
-        prepared_out[it.idx] = (n & 0x00ffffffu) | ((axis * 10u) << 24);
+        if (prepared_out) {
+            const uint64_t at = vr_treelet_address(it.idx + 1, it.depth);
+            if (at >= prepared_words) return VR_EARG;
+            prepared_out[at] = word;
+        }
+        if (leaf) continue;
         Item l = it, r = it;
         l.idx = 2 * it.idx + 1; r.idx = 2 * it.idx + 2;
         l.depth = r.depth = it.depth + 1;

@@ -14,11 +14,16 @@
  *       the iso value, so it runs once per view; rays that enter the volume are written, in tile
  *       order, to a dense list (direction, entry t, pixel).
  *    2. frames are zero-filled (OOB and miss pixels are black, src/raytrace.zig:54,67).
- *    3. persistent trace kernel: waves pull rays of one iso value at a time from that iso's queue
- *       and REFILL idle lanes as their rays finish, so lanes stay busy although ray lengths vary by
- *       three orders of magnitude.  Traversal resumes from the lowest valid ancestor after each
- *       MOVE (path stack in LDS) instead of restarting at the root.  Only hit pixels are stored.
+ *    3. persistent trace kernel, one 1024-thread block per CU: the top 14 levels of the tree (which
+ *       take two thirds of all node reads) sit in LDS, because what bounds this path on the chip is
+ *       the vector L1's rate for 64-address gathers, not HBM and not the VALU.  Waves pull rays of
+ *       one iso value at a time from that iso's queue and refill idle lanes as their rays finish.
+ *       Traversal resumes from the lowest valid ancestor after each MOVE (path stack in LDS) instead
+ *       of restarting at the root.  Only hit pixels are stored.
  */
+#include <cstdio>
+#include <cstdlib>
+
 #include "vr_internal.h"
 
 namespace {
@@ -26,11 +31,23 @@ namespace {
 constexpr uint32_t kTileW = 8, kTileH = 8;     /* pixels per wave                         */
 constexpr uint32_t kBlockW = 16, kBlockH = 16; /* pixels per 256-thread block (2x2 waves) */
 constexpr uint32_t kTopNodes = 4095;           /* heap levels 0..11, 16 KiB of LDS        */
-constexpr uint32_t kRefillMin = 16;            /* refill a wave once this many lanes idle */
+#ifndef VR_REFILL_MIN
+#define VR_REFILL_MIN 16
+#endif
+constexpr uint32_t kRefillMin = VR_REFILL_MIN; /* refill a wave once this many lanes idle */
 
 struct GlobalFetch {
     const uint32_t *nodes;
-    __device__ __forceinline__ uint32_t operator()(uint32_t idx) const { return nodes[idx]; }
+    __device__ __forceinline__ uint32_t operator()(uint32_t idx) const
+    {
+#if defined(VR_TUNE_SC1)
+        return __hip_atomic_load(nodes + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* bypasses the vector L1 */
+#elif defined(VR_TUNE_NT)
+        return __builtin_nontemporal_load(nodes + idx);
+#else
+        return nodes[idx];
+#endif
+    }
 };
 
 struct TopLdsFetch {
@@ -72,9 +89,10 @@ __device__ __forceinline__ void add_stat(uint64_t *p, unsigned long long v)
 /* ------------------------------------------------------------------ per-pixel kernels ---- */
 
 template <int VARIANT>
-__global__ __launch_bounds__(256) void vr_k_render(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t iso_begin,
-                                                   uint32_t row_begin, uint32_t n_rows, uint8_t *__restrict__ rgb,
-                                                   vr_render_stats *__restrict__ stats, VrTapsK taps)
+__global__ __launch_bounds__(256) void vr_k_render(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t max_depth,
+                                                   uint32_t iso_begin, uint32_t row_begin, uint32_t n_rows,
+                                                   uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
+                                                   VrTapsK taps)
 {
     __shared__ uint32_t s_top[VARIANT == VR_KERNEL_RESTART_LDS ? kTopNodes : 1];
     extern __shared__ uint32_t s_dyn[]; /* resume variant: path stack, [levels][256] */
@@ -231,21 +249,48 @@ __global__ void vr_k_tap_defaults(VrTapsK taps, uint64_t n)
 
 /* --------------------------------------------------------- pipeline: persistent trace ---- */
 
-template <bool TAPS>
-__global__ __launch_bounds__(256) void vr_k_trace(VrViewK v, const uint32_t *__restrict__ nodes,
-                                                  const float4 *__restrict__ ray_dt, const uint32_t *__restrict__ ray_pix,
-                                                  const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ heads,
-                                                  uint32_t iso_begin, uint32_t iso_count, uint64_t frame_pixels,
-                                                  uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats, VrTapsK taps)
+#ifdef VR_DIAG /* diagnostic build only: where a wave's cycles go (never compiled into the product library) */
+__device__ unsigned long long g_diag[16];
+__device__ __forceinline__ uint32_t wave_max(uint32_t x)
 {
-    extern __shared__ uint32_t s_dyn[]; /* path stack, [levels][256] */
-    LdsStack stack{ s_dyn + threadIdx.x, 256u };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { uint32_t y = __shfl_xor(x, off, 64); x = y > x ? y : x; }
+    return x;
+}
+#define DIAG_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define DIAG_ADD(i, val) d_acc[i] += (unsigned long long)(val)
+#else
+#define DIAG_T(var)
+#define DIAG_ADD(i, val)
+#endif
+
+constexpr uint32_t kTraceThreads = 256; /* 4 waves per block; blocks per CU set by the stack's LDS footprint */
+
+template <bool TAPS>
+__global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t max_depth,
+                                                            const float4 *__restrict__ ray_dt,
+                                                            const uint32_t *__restrict__ ray_pix,
+                                                            const uint32_t *__restrict__ n_active_ptr,
+                                                            uint32_t *__restrict__ heads, uint32_t iso_begin,
+                                                            uint32_t iso_count, uint64_t frame_pixels,
+                                                            uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
+                                                            VrTapsK taps)
+{
+    extern __shared__ uint32_t s_dyn[]; /* path stack: [levels][kTraceThreads] words */
+    LdsStack stack{ s_dyn + threadIdx.x, kTraceThreads };
+    const GlobalFetch fetch{ nodes };
+
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_active = *n_active_ptr;
-    const uint32_t n_waves = gridDim.x * 4u, gw = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t waves_per_block = kTraceThreads / 64u;
+    const uint32_t n_waves = gridDim.x * waves_per_block, gw = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     /* spread the waves over the iso queues; each wave then walks all queues cyclically, so waves that
      * run out of work on a cheap iso value move on to help with the expensive ones */
     const uint32_t k0 = (uint32_t)(((uint64_t)gw * iso_count) / n_waves);
+#ifdef VR_DIAG
+    unsigned long long d_acc[16] = { 0 };
+    DIAG_T(d_begin);
+#endif
 
     for (uint32_t visit = 0; visit < iso_count; visit++) {
         uint32_t k = k0 + visit;
@@ -261,6 +306,7 @@ __global__ __launch_bounds__(256) void vr_k_trace(VrViewK v, const uint32_t *__r
         uint32_t a_hit = 0, a_miss = 0, a_moves = 0, a_esc = 0, a_err = 0;
 
         for (;;) {
+            DIAG_T(d_t0);
             /* ---- refill idle lanes from this iso value's queue ---- */
             const unsigned long long idle = __ballot(!alive);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -276,37 +322,65 @@ __global__ __launch_bounds__(256) void vr_k_trace(VrViewK v, const uint32_t *__r
                     alive = true;
                 }
                 exhausted = base + n_idle >= n_active;
+                DIAG_ADD(12, 1);
             }
             if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
+            DIAG_T(d_t1);
+            DIAG_ADD(0, d_t1 - d_t0);
+            DIAG_ADD(5, 1);
+            DIAG_ADD(10, __popcll(__ballot(alive)));
+#ifdef VR_DIAG
+            uint32_t d_trips = 0, d_pops = 0;
+#endif
 
+            bool holds = false;
             if (alive) {
                 /* ---- descend while the node's density range holds the iso value ---- */
-                uint32_t n;
-                bool holds;
-                for (;;) {
-                    n = nodes[L.idx];
-                    L.checked++;
-                    holds = vr_node_holds(n, iso);
-                    if (!holds || (n & VR_N_LEAF)) break;
-                    vr_lane_zoom(L, n, stack);
-                }
+#ifdef VR_DIAG
+                d_trips = L.depth;
+#endif
+                holds = vr_lane_descend(L, iso, fetch, stack);
+#ifdef VR_DIAG
+                d_trips = L.depth + 1u - d_trips; /* levels visited */
+                d_pops = L.depth;
+#endif
+            }
+#ifdef VR_DIAG
+            { DIAG_T(d_t2); DIAG_ADD(2, d_t2 - d_t1); } /* wave-level: the whole descend phase */
+            bool d_did_move = false;
+#endif
+            if (alive) {
                 if (holds) { /* hit: shade and store (src/raytrace.zig:56-61) */
                     const uint8_t g = vr_shade(L.t);
-                    frame[(uint64_t)pix * 3u + 0u] = g;
-                    frame[(uint64_t)pix * 3u + 1u] = g;
-                    frame[(uint64_t)pix * 3u + 2u] = g;
+#ifdef VR_TUNE_NO_STORE
+                    if (g == 1)
+#endif
+                    {
+                        frame[(uint64_t)pix * 3u + 0u] = g;
+                        frame[(uint64_t)pix * 3u + 1u] = g;
+                        frame[(uint64_t)pix * 3u + 2u] = g;
+                    }
                     a_hit++;
                     alive = false;
                     if (TAPS) {
                         if (taps.cell_flag) taps.cell_flag[tap_base + pix] = vr_unpack_cell(L.cell) | (VR_FLAG_HIT << 24);
-                        if (taps.node) taps.node[tap_base + pix] = L.idx;
+                        if (taps.node) taps.node[tap_base + pix] = L.g - 1u;
                     }
                 } else {
                     a_moves++;
+#ifdef VR_DIAG
+                    d_did_move = true;
+#endif
                     bool in_root = vr_lane_move(L, v, a_esc);
                     if (L.checked > VR_MAX_CHECKED) { in_root = false; a_err++; }
+#ifdef VR_DIAG
+                    if (__builtin_amdgcn_readfirstlane(1)) { DIAG_T(d_tm); d_acc[3] += d_tm; }
+#endif
                     if (in_root) {
                         vr_lane_pop(L, stack);
+#ifdef VR_DIAG
+                        d_pops = d_pops + 1u - L.depth; /* levels popped */
+#endif
                     } else { /* left the volume: a miss, the pixel stays black (src/raytrace.zig:66-68) */
                         a_miss++;
                         alive = false;
@@ -324,6 +398,16 @@ __global__ __launch_bounds__(256) void vr_k_trace(VrViewK v, const uint32_t *__r
                     }
                 }
             }
+#ifdef VR_DIAG
+            {
+                DIAG_T(d_t3);
+                DIAG_ADD(1, d_t3 - d_t1); /* everything after the refill */
+                if (__ballot(d_did_move)) { DIAG_ADD(4, d_t3); DIAG_ADD(14, 1); } /* d_acc[4]-d_acc[3] = pop phase + tail */
+                if (!alive) d_pops = 0;
+                const uint32_t m1 = wave_max(d_trips), s1 = wave_sum(d_trips), m2 = wave_max(d_pops), s2 = wave_sum(d_pops);
+                DIAG_ADD(6, m1); DIAG_ADD(7, s1); DIAG_ADD(8, m2); DIAG_ADD(9, s2);
+            }
+#endif
         }
 
         /* ---- per-iso counters: one atomic per wave and counter ---- */
@@ -342,6 +426,15 @@ __global__ __launch_bounds__(256) void vr_k_trace(VrViewK v, const uint32_t *__r
             }
         }
     }
+#ifdef VR_DIAG
+    {
+        DIAG_T(d_end);
+        d_acc[11] = d_end - d_begin;
+        d_acc[13] = 1;
+        if (lane == 0)
+            for (int i = 0; i < 16; i++) atomicAdd(&g_diag[i], d_acc[i]);
+    }
+#endif
 }
 
 } // namespace
@@ -376,16 +469,16 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
         if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
         switch (variant) {
         case VR_KERNEL_RESTART_GLOBAL:
-            hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESTART_GLOBAL>, grid, block, 0, stream, view, d_nodes_raw, iso_begin,
-                               row_begin, n_rows, d_rgb, d_stats, taps);
+            hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESTART_GLOBAL>, grid, block, 0, stream, view, d_nodes_raw, max_depth,
+                               iso_begin, row_begin, n_rows, d_rgb, d_stats, taps);
             break;
         case VR_KERNEL_RESTART_LDS:
-            hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESTART_LDS>, grid, block, 0, stream, view, d_nodes_raw, iso_begin,
-                               row_begin, n_rows, d_rgb, d_stats, taps);
+            hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESTART_LDS>, grid, block, 0, stream, view, d_nodes_raw, max_depth,
+                               iso_begin, row_begin, n_rows, d_rgb, d_stats, taps);
             break;
         default:
             hipLaunchKernelGGL(vr_k_render<VR_KERNEL_RESUME>, grid, block, stack_bytes, stream, view, d_nodes_prepared,
-                               iso_begin, row_begin, n_rows, d_rgb, d_stats, taps);
+                               max_depth, iso_begin, row_begin, n_rows, d_rgb, d_stats, taps);
             break;
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -422,30 +515,42 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     if (any_tap) hipLaunchKernelGGL(vr_k_tap_defaults, dim3(2048), dim3(256), 0, stream, taps, (uint64_t)n_pix * iso_count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
 
-    /* persistent grid: as many blocks as stay resident (8 blocks of 4 waves fill a CU's 32 wave slots) */
-    static size_t occ_key[2] = { ~(size_t)0, ~(size_t)0 };
-    static int occ_val[2] = { 0, 0 };
-    const int ti = any_tap ? 1 : 0;
-    if (occ_key[ti] != stack_bytes) {
-        int occ = 0;
-        if (any_tap)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vr_k_trace<true>, 256, stack_bytes);
-        else
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vr_k_trace<false>, 256, stack_bytes);
-        if (e != hipSuccess) return e;
-        occ_val[ti] = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
-        occ_key[ti] = stack_bytes;
+    /* persistent grid: as many 256-thread blocks per CU as the path stacks leave room for in LDS
+     * (8 blocks = the CU's 32 wave slots). */
+    const void *fn = any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>;
+    int per_cu = 0;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)kTraceThreads, stack_bytes)) != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    if (const char *tune = getenv("VR_TUNE_BLOCKS_PER_CU")) { /* experiment knob: fewer resident blocks */
+        const int b = atoi(tune);
+        if (b >= 1 && b <= per_cu) per_cu = b;
     }
-    const uint32_t blocks = (uint32_t)n_cus * (uint32_t)occ_val[ti];
+    const uint32_t blocks = (uint32_t)n_cus * (uint32_t)per_cu;
+    const uint64_t frame_pixels = n_pix;
+    void *args[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&max_depth, (void *)&ray_dt, (void *)&ray_pix,
+                     (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
+                     (void *)&d_rgb, (void *)&d_stats, (void *)&taps };
 
     if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
-    if (any_tap)
-        hipLaunchKernelGGL(vr_k_trace<true>, dim3(blocks), dim3(256), stack_bytes, stream, view, d_nodes_prepared, ray_dt,
-                           ray_pix, n_active, heads, iso_begin, iso_count, (uint64_t)n_pix, d_rgb, d_stats, taps);
-    else
-        hipLaunchKernelGGL(vr_k_trace<false>, dim3(blocks), dim3(256), stack_bytes, stream, view, d_nodes_prepared, ray_dt,
-                           ray_pix, n_active, heads, iso_begin, iso_count, (uint64_t)n_pix, d_rgb, d_stats, taps);
+    if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, stack_bytes, stream)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+#ifdef VR_DIAG
+    {
+        unsigned long long h[16], z[16] = { 0 };
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z);
+        const double w = (double)h[13], it = (double)h[5];
+        fprintf(stderr,
+                "[diag] waves %.0f  cycles/wave %.0f  outer its/wave %.0f  refill events/wave %.0f\n"
+                "[diag] per outer it: refill %.0f cyc, rest %.0f cyc; alive lanes %.1f\n"
+                "[diag] descend trips: wave %.2f lane-mean %.2f ; pops: wave %.2f lane-mean %.2f\n"
+                "[diag] per outer it: descend phase %.0f cyc, move..end-of-pop %.0f cyc (%.0f%% of its had a move)\n",
+                w, h[11] / w, it / w, h[12] / w, h[0] / it, h[1] / it, h[10] / it, h[6] / it, h[7] / (double)h[10],
+                h[8] / it, h[9] / (double)h[10], h[2] / it, (double)(h[4] - h[3]) / (double)h[14], 100.0 * h[14] / it);
+    }
+#endif
     return hipSuccess;
 }

@@ -21,8 +21,8 @@
 #include <math.h>
 #include <stdint.h>
 
-#if defined(__HIPCC__)
-#define VR_HD __host__ __device__ __forceinline__
+#if defined(__HIP__) /* compiled as HIP source: usable from kernels */
+#define VR_HD __attribute__((host)) __attribute__((device)) inline __attribute__((always_inline))
 #else
 #define VR_HD inline
 #endif
@@ -204,28 +204,63 @@ VR_HD VrHit vr_trace_restart(const VrViewK &v, const VrRay &ray, uint32_t iso, N
  * just skipped passed its iso test, and the child choice at each level is a pure function of the
  * point, so the new walk follows the old path down to the lowest ancestor whose box still holds
  * the new point -- node for node.  This variant therefore keeps the path (one word per level),
- * pops ancestors until the box holds the new point, credits the `depth` node checks the reference
- * would have spent getting there, and carries on from that ancestor.  Hit cell, t, flags and the
+ * pops ancestors until the box holds the new point, credits the node checks the reference would
+ * have spent getting there, and carries on from there.  Hit cell, t, flags and the
  * reference-defined checked count are identical; far fewer nodes are read.
  *
- * It walks the PREPARED node array (vr_host_prepare_kdt): the reference's SlimNode word with the
- * axis replaced by the field shift (axis * 10) and a leaf flag, produced by a validating walk that
- * guarantees every reachable inner node splits strictly inside its box.  That guarantee is what
- * lets the loops below run without index, axis or depth checks.
+ * It walks the PREPARED node array (vr_host_prepare_kdt): produced by a validating walk that
+ * guarantees every reachable inner node splits strictly inside its box, which is what lets the
+ * loops below run without index, axis or depth checks.
  *
- *   bits 0-7 min | 8-15 max | 16-23 partition | 24-28 shift | 31 leaf
+ * Layout of the prepared array: TREELETS.  What bounds this traversal on the GPU is the number of
+ * distinct cache lines a wave's gathers touch (L1 misses), and in the reference's breadth-first heap
+ * every level of a descent lies in a different line.  So the heap is cut into subtrees of 5 levels
+ * (31 nodes) and each subtree is stored in one 128-byte line: a descent touches one line per five
+ * levels.  With g = heap index + 1 (root = 1, children 2g and 2g+1) and depth d = 5q + r:
+ *   treelet root   g >> r, the k-th node (k = (g >> r) - 32^q) of level 5q
+ *   treelet id     (32^q - 1) / 31 + k  =  (g >> r) - C(q),   C(q) = (30 * 32^q + 1) / 31
+ *   word address   32 * id + j,   j = (1 << r) | (g & ((1 << r) - 1))   (local heap index 1..31)
+ * C obeys C(0) = 1, C(q+1) = 32 C(q) - 1, so the lane keeps (treelet base, j, C) and updates them
+ * with a few integer operations per level.  Word format:
+ *
+ *   bits 0-7 min | 8-15 max | 16-23 partition | 24-28 shift (axis * 10) | 31 leaf
  *
  * Stack word per level: the packed bound word (lo or hi) the zoom replaced.  `Stack` provides
- * push(level, word) / pop(level).
+ * push(level, word) / pop(level).  `Fetch` provides operator()(word address).
  * ---------------------------------------------------------------------------------------- */
 #define VR_N_LEAF 0x80000000u
 #define VR_MAX_CHECKED (1u << 27) /* safety valve per ray; a 256^3 volume stays far below it */
+#define VR_TREELET_LEVELS 5u
+#define VR_TREELET_WORDS 32u
+
+/* number of 32-word treelets that cover levels 0..max_depth */
+VR_HD uint64_t vr_treelet_count(uint32_t max_depth)
+{
+    uint64_t n = 0, per_level = 1;
+    for (uint32_t q = 0; q <= max_depth / VR_TREELET_LEVELS; q++) { n += per_level; per_level *= 32u; }
+    return n;
+}
+
+/* word address of heap position g (1-based) at depth d: the closed form of the layout above */
+VR_HD uint64_t vr_treelet_address(uint64_t g, uint32_t d)
+{
+    const uint32_t q = d / VR_TREELET_LEVELS, r = d % VR_TREELET_LEVELS;
+    uint64_t c = 1; /* C(q) */
+    for (uint32_t i = 0; i < q; i++) c = 32u * c - 1u;
+    const uint64_t id = (g >> r) - c;
+    const uint64_t j = ((uint64_t)1 << r) | (g & (((uint64_t)1 << r) - 1u));
+    return VR_TREELET_WORDS * id + j;
+}
 
 struct VrLane {
     float dx, dy, dz, t;
     uint32_t cell;    /* packed floor(point), valid while the point is inside the root box */
     uint32_t lo, hi;  /* packed box of the current node */
-    uint32_t idx, depth;
+    uint32_t g;       /* 1-based heap position of the current node */
+    uint32_t depth;
+    uint32_t tb;      /* word address of the current treelet */
+    uint32_t j;       /* local heap index inside the treelet, 1..31 */
+    uint32_t cq;      /* C(depth / 5) */
     uint32_t posmask; /* 0x3ff in the field of every axis the ray travels in the + direction */
     uint32_t checked; /* reference-defined node checks of this ray */
 };
@@ -236,7 +271,8 @@ VR_HD void vr_lane_begin(VrLane &L, const VrViewK &v, float dx, float dy, float 
     /* inside the root box every coordinate is >= 0, so trunc == floor */
     L.cell = vr_pack10((uint32_t)(v.ox + dx * t), (uint32_t)(v.oy + dy * t), (uint32_t)(v.oz + dz * t));
     L.lo = 0; L.hi = v.root_hi;
-    L.idx = 0; L.depth = 0; L.checked = 0;
+    L.g = 1; L.depth = 0; L.checked = 0;
+    L.tb = 0; L.j = 1; L.cq = 1;
     L.posmask = (dx >= 0.0f ? 0x3ffu : 0u) | (dy >= 0.0f ? (0x3ffu << 10) : 0u) | (dz >= 0.0f ? (0x3ffu << 20) : 0u);
 }
 
@@ -254,8 +290,29 @@ VR_HD void vr_lane_zoom(VrLane &L, uint32_t n, Stack &stack)
     side = (side & ~(0xffu << sh)) | (part << sh); /* partition is strictly inside the box: min/max of geo.zig:256-275 pick it */
     L.hi = left ? side : L.hi;
     L.lo = left ? L.lo : side;
-    L.idx = 2u * L.idx + (left ? 1u : 2u);
+    const uint32_t b = left ? 0u : 1u;
+    L.g = 2u * L.g + b;
     L.depth++;
+    /* treelet bookkeeping: a child of the treelet's bottom level is the root of a new treelet */
+    const uint32_t j2 = 2u * L.j + b;
+    const bool cross = j2 >= VR_TREELET_WORDS;
+    const uint32_t cn = (L.cq << 5) - 1u;
+    L.cq = cross ? cn : L.cq;
+    L.tb = cross ? ((L.g - cn) << 5) : L.tb;
+    L.j = cross ? 1u : j2;
+}
+
+/* recomputes (tb, j, cq) from (g, depth) */
+VR_HD void vr_lane_locate(VrLane &L)
+{
+    const uint32_t q = (L.depth * 13u) >> 6; /* depth / 5 for depth < 64 */
+    const uint32_t r = L.depth - 5u * q;
+    const uint32_t sh = 5u * q;
+    const uint32_t c = (1u << sh) - (0x42108421u & ((1u << sh) - 1u)); /* C(q) = 32^q - (32^q - 1) / 31 */
+    const uint32_t root = L.g >> r;
+    L.cq = c;
+    L.tb = (root - c) << 5;
+    L.j = L.g - (root << r) + (1u << r);
 }
 
 /* MOVE (src/raytrace.zig:199-205) + escape help (:233-242).  Returns false when the new point is
@@ -284,27 +341,65 @@ VR_HD bool vr_lane_move(VrLane &L, const VrViewK &v, uint32_t &escapes)
     return in_root;
 }
 
-/* Pops ancestors until the box holds the new point, then credits the checks the reference spends
- * walking root .. parent(ancestor) again.  Precondition: the point is inside the root box and
- * outside the current box. */
+/* After a MOVE: pops ancestors until one holds the new point, then steps straight into that
+ * ancestor's OTHER child.  (The ancestor A holds the point, its child C on the old path does not, and
+ * A's two children tile A, so the point is in C's sibling; A itself passed its iso test on the way
+ * down, so the reference's restarted walk goes root .. A .. sibling.  A is not read again: the split
+ * field is the one where A's and C's cut bound differ, and the partition is C's value there.)
+ * Credits the depth(A)+1 node checks the reference spends on root .. A.  The stack word of the next
+ * level up is requested before the current one is examined, so its latency hides behind the test.
+ * Precondition: the point is inside the root box and outside the current box (so depth >= 1). */
 template <class Stack>
 VR_HD void vr_lane_pop(VrLane &L, Stack &stack)
 {
-    while (L.depth > 0) {
-        L.depth--;
-        const uint32_t word = stack.pop(L.depth);
-        if (L.idx & 1u) L.hi = word; else L.lo = word; /* odd index = left child: the zoom had cut hi */
-        L.idx = (L.idx - 1u) >> 1;
-        if (vr_box_contains_cell(L.lo, L.hi, L.cell)) break;
+    uint32_t next = stack.pop(L.depth - 1u);
+    for (;;) {
+        L.depth--; /* level of the parent A */
+        const uint32_t word = next; /* A's bound word that the zoom into C replaced */
+        next = stack.pop(L.depth > 0u ? L.depth - 1u : 0u);
+        const bool left = (L.g & 1u) == 0u;       /* even position = left child: the zoom had cut hi */
+        const uint32_t cut = left ? L.hi : L.lo;  /* C's cut side */
+        const uint32_t keep = left ? L.lo : L.hi; /* the side C shares with A */
+        const uint32_t a_lo = left ? keep : word, a_hi = left ? word : keep;
+        if (vr_box_contains_cell(a_lo, a_hi, L.cell)) {
+            const uint32_t diff = word ^ cut;
+            const uint32_t fm = (diff & 0x3ffu) ? 0x3ffu : ((diff & 0xffc00u) ? 0xffc00u : 0x3ff00000u);
+            const uint32_t other = (keep & ~fm) | (cut & fm); /* sibling's new bound on the side it cuts */
+            stack.push(L.depth, keep);
+            L.lo = left ? other : a_lo;
+            L.hi = left ? a_hi : other;
+            L.g ^= 1u;
+            L.depth++;
+            L.checked += L.depth;
+            vr_lane_locate(L);
+            return;
+        }
+        L.lo = a_lo;
+        L.hi = a_hi;
+        L.g >>= 1;
     }
-    L.checked += L.depth;
 }
 
 VR_HD uint32_t vr_unpack_cell(uint32_t c10) { return (c10 & 0xffu) | (((c10 >> 10) & 0xffu) << 8) | (((c10 >> 20) & 0xffu) << 16); }
 
+/* Descends from the current node while the node's density range holds the iso value
+ * (src/raytrace.zig:161-194).  Returns true on a hit (a leaf whose range holds the iso value), false
+ * when the node at L.g excludes it (-> MOVE). */
+template <class Fetch, class Stack>
+VR_HD bool vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stack &stack)
+{
+    for (;;) {
+        const uint32_t n = fetch(L.tb + L.j);
+        L.checked++;
+        const bool holds = vr_node_holds(n, iso);
+        if (!holds || (n & VR_N_LEAF)) return holds;
+        vr_lane_zoom(L, n, stack);
+    }
+}
+
 /* one ray from entry to hit or miss; `fetch` reads the PREPARED node array */
-template <class NodeFetch, class Stack>
-VR_HD VrHit vr_trace_resume(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Stack &stack)
+template <class Fetch, class Stack>
+VR_HD VrHit vr_trace_resume(const VrViewK &v, const VrRay &ray, uint32_t iso, const Fetch &fetch, Stack &stack)
 {
     VrHit h;
     h.t = 0.0f; h.flag = 2u; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
@@ -313,17 +408,9 @@ VR_HD VrHit vr_trace_resume(const VrViewK &v, const VrRay &ray, uint32_t iso, No
     vr_lane_begin(L, v, ray.dx, ray.dy, ray.dz, ray.t);
     h.flag = 0u;
     for (;;) {
-        uint32_t n;
-        bool holds;
-        for (;;) { /* descend while the node's density range holds the iso value */
-            n = fetch(L.idx);
-            L.checked++;
-            holds = vr_node_holds(n, iso);
-            if (!holds || (n & VR_N_LEAF)) break;
-            vr_lane_zoom(L, n, stack);
-        }
-        if (holds) { /* a leaf cell whose range holds the iso value: the hit (src/raytrace.zig:178-187) */
-            h.flag = 1u; h.node = L.idx; h.cell = vr_unpack_cell(L.cell);
+        if (vr_lane_descend(L, iso, fetch, stack)) {
+            /* a leaf cell whose range holds the iso value: the hit (src/raytrace.zig:178-187) */
+            h.flag = 1u; h.node = L.g - 1u; h.cell = vr_unpack_cell(L.cell);
             break;
         }
         h.moves++;
