@@ -125,14 +125,11 @@ int vr_host_build_kdt(const uint8_t *vox, const uint32_t res[3], int heuristic, 
  * reference's builder always produces; anything else never reaches a leaf in the reference's zoom
  * either: VR_ETREE), and writes the array the kernels walk:
  *   word    bits 0-23 unchanged (min, max, partition), bits 24-28 = axis * 10, bit 31 = leaf
- *   layout  5-level subtrees ("treelets", 31 nodes) stored in one 128-byte line each, so a descent
- *           touches one cache line per five levels instead of one per level.  With g = heap index
- *           + 1 at depth d = 5q + r: word address = 32 * ((g >> r) - C(q)) + ((1 << r) | (g & ((1 <<
- *           r) - 1))), C(q) = (30 * 32^q + 1) / 31.  Unoccupied words are 0.
- * Call once with prepared_out = NULL to validate and learn max_depth (root = 0), allocate
- * vr_prepared_words(max_depth) words, call again to fill them.  Trees deeper than 29 levels give
- * VR_ETOODEEP. */
-uint64_t vr_prepared_words(uint32_t max_depth);
+ *   layout  the same heap, 1-based: the node at heap index i goes to position i + 1 (children of
+ *           position g at 2g and 2g + 1, parent g >> 1, sibling g ^ 1); unoccupied words are 0.
+ * prepared_out may be NULL (validate only); otherwise it must hold prepared_words =
+ * vr_prepared_words(n_slots) words.  max_depth_out = deepest level (root = 0). */
+uint64_t vr_prepared_words(uint64_t n_slots);
 int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3],
                         uint32_t *prepared_out, uint64_t prepared_words, uint32_t *max_depth_out,
                         uint64_t *n_nodes_out);

@@ -14,9 +14,13 @@ struct HostFetch {
     uint32_t operator()(uint32_t i) const { return nodes[i]; }
 };
 struct HostStack {
-    uint32_t word[VR_MAX_DEPTH + 1];
-    void push(uint32_t level, uint32_t w) { word[level] = w; }
-    uint32_t pop(uint32_t level) const { return word[level]; }
+    uint32_t word[VR_MAX_DEPTH + 3];
+    int cur = 1; /* one spare slot above the root, as on the device */
+    void reset() { cur = 1; }
+    void push(uint32_t w) { word[cur++] = w; }
+    void up() { cur--; }
+    uint32_t peek_up(uint32_t k) const { return word[cur - (int)k]; }
+    uint32_t depth() const { return (uint32_t)(cur - 1); }
 };
 } // namespace
 
@@ -68,4 +72,31 @@ extern "C" int vr_emu_render(int variant, const uint32_t *nodes, uint64_t n_slot
             sums[6] += h.error;
         }
     return 0;
+}
+
+/* vr_div (reciprocal + two FMA corrections) against the IEEE divide on the operand range of the MOVE step:
+ * numerator = plane offset (0..255) - camera coordinate, denominator = a component of a unit direction with
+ * |d| >= 1e-8.  Returns the number of operand pairs whose results differ in any bit. */
+extern "C" uint64_t vr_emu_div_check(uint64_t samples, uint64_t seed)
+{
+    uint64_t s = seed ? seed : 88172645463325252ull, bad = 0;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    auto urand = [&]() { return (float)((rnd() >> 40) * (1.0 / 16777216.0)); };
+    for (uint64_t i = 0; i < samples; i++) {
+        float d;
+        const uint32_t mode = (uint32_t)(rnd() & 3u);
+        if (mode == 0) d = urand() * 2.0f - 1.0f;
+        else if (mode == 1) d = ldexpf(urand() + 0.5f, -(int)(rnd() % 27u)) * ((rnd() & 1u) ? 1.0f : -1.0f);
+        else { uint32_t b = 0x3f800000u - (uint32_t)(rnd() % (27u << 23)); std::memcpy(&d, &b, 4); if (rnd() & 1u) d = -d; }
+        if (!(fabsf(d) >= 1e-8f) || fabsf(d) > 1.0f) continue;
+        float o;
+        const uint32_t om = (uint32_t)(rnd() % 3u);
+        if (om == 0) o = (urand() * 2.0f - 1.0f) * 1000.0f;
+        else if (om == 1) o = (float)((int)(rnd() % 2001u) - 1000) * 0.5f;
+        else o = (urand() * 2.0f - 1.0f) * 300.0f;
+        const float n = (float)(rnd() % 256u) - o;
+        const float q = n / d, m = vr_div(n, d, 1.0f / d);
+        if (std::memcmp(&q, &m, 4) != 0 && !(q == 0.0f && m == 0.0f)) bad++;
+    }
+    return bad;
 }

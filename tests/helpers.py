@@ -4,29 +4,17 @@ import numpy as np
 
 
 def prepare_nodes(nodes, rd):
-    """vr_host_prepare_kdt of the product library (host-only): validated node words in treelet layout."""
+    """vr_host_prepare_kdt of the product library (host-only): validated node words, 1-based heap."""
     from volumerenderer_amd import capi
     L = capi.lib()
     nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
     rd3 = (C.c_uint8 * 3)(*[int(x) for x in rd])
     depth = C.c_uint32()
     count = C.c_uint64()
-    rc = L.vr_host_prepare_kdt(nodes.ctypes.data, len(nodes), rd3, None, 0, C.byref(depth), C.byref(count))
-    if rc != 0:
-        return rc, None, 0, 0
-    out = np.zeros(L.vr_prepared_words(depth.value), dtype=np.uint32)
+    out = np.zeros(L.vr_prepared_words(len(nodes)), dtype=np.uint32)
     rc = L.vr_host_prepare_kdt(nodes.ctypes.data, len(nodes), rd3, out.ctypes.data, len(out), C.byref(depth),
                                C.byref(count))
     return rc, out, depth.value, count.value
-
-
-def treelet_address(g, d):
-    """word address of 1-based heap position g at depth d in the prepared (treelet) layout"""
-    q, r = divmod(d, 5)
-    c = 1
-    for _ in range(q):
-        c = 32 * c - 1
-    return 32 * ((g >> r) - c) + ((1 << r) | (g & ((1 << r) - 1)))
 
 
 def emu_render(L, variant, nodes, rd, pos, f, u, w, h, vp, iso):

@@ -105,29 +105,22 @@ def test_main_camera_matches_oracle(oracle):
 
 
 def test_prepare_kdt_flattens_and_validates(oracle, c60_tree):
-    from helpers import prepare_nodes, treelet_address
+    from helpers import prepare_nodes
     nodes, rd, st = c60_tree
     rc, prep, depth, count = prepare_nodes(nodes, rd)
     assert rc == 0 and depth == st.layer_count and count == st.number_of_nodes
-    assert len(prep) == 32 * (1 + 32 + 32 ** 2 + 32 ** 3)                # treelets covering levels 0..19
-    assert int((prep != 0).sum()) == count
-    assert int(((prep >> 31) == 1).sum()) == 63 ** 3                     # one leaf per cell
-    # spot-check the layout: every used heap slot sits at its treelet address with min/max/partition intact
-    rng = np.random.default_rng(5)
-    used = np.flatnonzero(nodes)
-    for i in [0, 1, 2, 30, 31, 62, 63] + list(rng.choice(used, 2000)):
-        g = int(i) + 1
-        d = g.bit_length() - 1
-        w = int(prep[treelet_address(g, d)])
-        assert (w & 0x00FFFFFF) == (int(nodes[i]) & 0x00FFFFFF)
-        if not (w >> 31):
-            assert ((w >> 24) & 31) == 10 * ((int(nodes[i]) >> 24) & 3)
-    # a 5-level subtree occupies one 32-word line: root at word 1, its 16 bottom nodes at words 16..31
-    assert treelet_address(1, 0) == 1 and treelet_address(31, 4) == 31 and treelet_address(32, 5) == 33
+    assert len(prep) == len(nodes) + 1 and prep[0] == 0                  # 1-based heap: position 0 is unused
+    prep = prep[1:]
+    assert ((prep & 0x00FFFFFF) == (nodes & 0x00FFFFFF)).all()          # min, max, partition untouched
+    used = prep != 0
+    leaf = (prep >> 31) == 1
+    assert int(leaf.sum()) == 63 ** 3                                    # one leaf per cell
+    inner = used & ~leaf
+    assert (((prep[inner] >> 24) & 31) == 10 * ((nodes[inner] >> 24) & 3)).all()
     # undefined upper bits of the Zig packed struct are ignored
     noisy = nodes | (np.uint32(0xFC) << 24)
     rc2, prep2, _, _ = prepare_nodes(noisy, rd)
-    assert rc2 == 0 and (prep2 == prep).all()
+    assert rc2 == 0 and (prep2[1:] == prep).all()
     # malformed trees are rejected: partition on the box edge, bad axis, truncated array
     bad = nodes.copy(); bad[0] = (bad[0] & ~np.uint32(0x00FF0000)) | (np.uint32(63) << 16)
     assert prepare_nodes(bad, rd)[0] == capi.VR_ETREE

@@ -90,7 +90,7 @@ def lib():
     L.vr_host_build_kdt.argtypes = [vp, u32p, C.c_int, C.c_uint64, C.POINTER(u32p), C.POINTER(C.c_uint64), u8p,
                                     C.POINTER(BuildStats)]
     L.vr_host_prepare_kdt.argtypes = [vp, C.c_uint64, u8p, vp, C.c_uint64, u32p, C.POINTER(C.c_uint64)]
-    L.vr_prepared_words.argtypes = [C.c_uint32]
+    L.vr_prepared_words.argtypes = [C.c_uint64]
     L.vr_prepared_words.restype = C.c_uint64
     L.vr_main_camera.argtypes = [u32p, f32p, f32p, f32p]
     L.vr_main_camera.restype = None

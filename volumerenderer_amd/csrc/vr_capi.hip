@@ -158,12 +158,10 @@ int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint
     if (root_dim[0] == 0 || root_dim[1] == 0 || root_dim[2] == 0) return VR_EARG;
     /* validate and flatten on the host before anything reaches the device */
     uint32_t max_depth = 0;
-    int rc = vr_host_prepare_kdt(nodes, n_slots, root_dim, nullptr, 0, &max_depth, nullptr);
-    if (rc != VR_OK) return rc;
-    const uint64_t prep_words = vr_prepared_words(max_depth);
+    const uint64_t prep_words = vr_prepared_words(n_slots);
     uint32_t *prepared = (uint32_t *)std::malloc(prep_words * sizeof(uint32_t));
     if (!prepared) return VR_ENOMEM;
-    rc = vr_host_prepare_kdt(nodes, n_slots, root_dim, prepared, prep_words, &max_depth, nullptr);
+    int rc = vr_host_prepare_kdt(nodes, n_slots, root_dim, prepared, prep_words, &max_depth, nullptr);
     if (rc != VR_OK) { std::free(prepared); return rc; }
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }

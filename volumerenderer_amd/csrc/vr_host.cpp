@@ -24,9 +24,6 @@
 #include <vector>
 
 #include "../../include/vr.h"
-#include "vr_trace_core.h"
-
-#define VR_MAX_PREPARED_DEPTH 29u /* treelet word addresses stay below 2^32 up to this depth */
 
 namespace {
 
@@ -294,9 +291,9 @@ void vr_main_camera(const uint32_t res[3], const float pos[3], float forw_out[3]
     for (int k = 0; k < 3; k++) { forw_out[k] = f[k]; up_out[k] = u[k]; }
 }
 
-uint64_t vr_prepared_words(uint32_t max_depth)
+uint64_t vr_prepared_words(uint64_t n_slots)
 {
-    return vr_treelet_count(max_depth) * VR_TREELET_WORDS;
+    return n_slots + 1; /* 1-based heap: the node at heap index i sits at position i + 1 */
 }
 
 int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], uint32_t *prepared_out,
@@ -319,7 +316,6 @@ int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t r
         Item it = todo.back();
         todo.pop_back();
         if (it.idx >= n_slots) return VR_ETREE; /* a descent would read past the array */
-        if (it.depth > VR_MAX_PREPARED_DEPTH) return VR_ETOODEEP;
         const uint32_t n = nodes[it.idx];
         const uint32_t axis = (n >> 24) & 3u, part = (n >> 16) & 0xffu;
         count++;
@@ -335,9 +331,8 @@ int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t r
             word = (n & 0x00ffffffu) | ((axis * 10u) << 24);
         }
         if (prepared_out) {
-            const uint64_t at = vr_treelet_address(it.idx + 1, it.depth);
-            if (at >= prepared_words) return VR_EARG;
-            prepared_out[at] = word;
+            if (it.idx + 1 >= prepared_words) return VR_EARG;
+            prepared_out[it.idx + 1] = word;
         }
         if (leaf) continue;
         Item l = it, r = it;

@@ -59,12 +59,34 @@ struct TopLdsFetch {
     }
 };
 
-/* path stack: one 32-bit word per level, one column per thread of the block: [level][thread] */
+/* path stack cursor: one 32-bit word per level, one column per thread of the block, [level][thread],
+ * preceded by one spare row so that looking one level above the root stays inside the allocation */
+template <uint32_t STRIDE>
 struct LdsStack {
-    uint32_t *col;
-    uint32_t stride;
-    __device__ __forceinline__ void push(uint32_t level, uint32_t word) { col[level * stride] = word; }
-    __device__ __forceinline__ uint32_t pop(uint32_t level) const { return col[level * stride]; }
+    uint32_t *base; /* level 0 of this thread's column */
+    uint32_t *sp;
+    __device__ __forceinline__ explicit LdsStack(uint32_t *dyn) : base(dyn + STRIDE + threadIdx.x), sp(base) {}
+    __device__ __forceinline__ void reset() { sp = base; }
+    __device__ __forceinline__ void push(uint32_t word) { *sp = word; sp += STRIDE; }
+    __device__ __forceinline__ void up() { sp -= STRIDE; }
+    __device__ __forceinline__ uint32_t peek_up(uint32_t k) const { return *(sp - k * STRIDE); }
+    __device__ __forceinline__ uint32_t depth() const { return (uint32_t)(sp - base) / STRIDE; }
+};
+
+/* heap positions below n_top come from the LDS copy of the top tree levels, deeper ones from global memory.
+ * The LDS read is unconditional (clamped index) and the global read sits behind a branch that the wave
+ * skips when no lane is that deep: written as a select of two pointers the compiler turns the pair into one
+ * flat load, which sends the LDS hits through the vector memory path as well. */
+struct TopFetch {
+    const uint32_t *nodes;
+    uint32_t n_top; /* > 0 */
+    __device__ __forceinline__ uint32_t operator()(uint32_t g) const
+    {
+        extern __shared__ uint32_t s_dyn[];
+        uint32_t n = s_dyn[g < n_top ? g : 0u];
+        if (g >= n_top) n = nodes[g];
+        return n;
+    }
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
@@ -120,7 +142,7 @@ __global__ __launch_bounds__(256) void vr_k_render(VrViewK v, const uint32_t *__
         } else if (VARIANT == VR_KERNEL_RESTART_LDS) {
             h = vr_trace_restart(v, ray, iso, TopLdsFetch{ nodes, s_top });
         } else {
-            LdsStack st{ s_dyn + threadIdx.x, 256u };
+            LdsStack<256u> st(s_dyn);
             h = vr_trace_resume(v, ray, iso, GlobalFetch{ nodes }, st);
         }
         const uint64_t pix = ((uint64_t)blockIdx.y * n_rows + yr) * v.width + xi;
@@ -264,10 +286,10 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t x)
 #define DIAG_ADD(i, val)
 #endif
 
-constexpr uint32_t kTraceThreads = 256; /* 4 waves per block; blocks per CU set by the stack's LDS footprint */
+constexpr uint32_t kTraceThreads = 1024; /* one block of 16 waves per CU */
 
 template <bool TAPS>
-__global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t max_depth,
+__global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top,
                                                             const float4 *__restrict__ ray_dt,
                                                             const uint32_t *__restrict__ ray_pix,
                                                             const uint32_t *__restrict__ n_active_ptr,
@@ -276,9 +298,12 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
                                                             uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
                                                             VrTapsK taps)
 {
-    extern __shared__ uint32_t s_dyn[]; /* path stack: [levels][kTraceThreads] words */
-    LdsStack stack{ s_dyn + threadIdx.x, kTraceThreads };
-    const GlobalFetch fetch{ nodes };
+    /* dynamic LDS: [n_top node words: heap positions 0 .. n_top-1][path stacks: (levels + 1) x kTraceThreads words] */
+    extern __shared__ uint32_t s_dyn[];
+    for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_dyn[i] = nodes[i];
+    __syncthreads();
+    LdsStack<kTraceThreads> stack(s_dyn + n_top);
+    const TopFetch fetch{ nodes, n_top };
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_active = *n_active_ptr;
@@ -318,7 +343,7 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
                 if (!alive && mine < n_active) {
                     const float4 r = ray_dt[mine];
                     pix = ray_pix[mine];
-                    vr_lane_begin(L, v, r.x, r.y, r.z, r.w);
+                    vr_lane_begin(L, stack, v, r.x, r.y, r.z, r.w);
                     alive = true;
                 }
                 exhausted = base + n_idle >= n_active;
@@ -337,12 +362,12 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
             if (alive) {
                 /* ---- descend while the node's density range holds the iso value ---- */
 #ifdef VR_DIAG
-                d_trips = L.depth;
+                d_trips = stack.depth();
 #endif
                 holds = vr_lane_descend(L, iso, fetch, stack);
 #ifdef VR_DIAG
-                d_trips = L.depth + 1u - d_trips; /* levels visited */
-                d_pops = L.depth;
+                d_trips = stack.depth() + 1u - d_trips; /* levels visited */
+                d_pops = stack.depth();
 #endif
             }
 #ifdef VR_DIAG
@@ -379,7 +404,7 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
                     if (in_root) {
                         vr_lane_pop(L, stack);
 #ifdef VR_DIAG
-                        d_pops = d_pops + 1u - L.depth; /* levels popped */
+                        d_pops = d_pops + 1u - stack.depth(); /* levels popped */
 #endif
                     } else { /* left the volume: a miss, the pixel stays black (src/raytrace.zig:66-68) */
                         a_miss++;
@@ -459,7 +484,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
 {
     const uint32_t n_rows = row_end - row_begin;
     const uint32_t stack_levels = max_depth > 0 ? max_depth : 1u;
-    const size_t stack_bytes = (size_t)stack_levels * 256u * sizeof(uint32_t);
+    const size_t stack_bytes = ((size_t)stack_levels + 1u) * 256u * sizeof(uint32_t); /* + the spare row above the root */
     hipError_t e;
 
     if (variant != VR_KERNEL_PIPELINE) {
@@ -515,25 +540,33 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     if (any_tap) hipLaunchKernelGGL(vr_k_tap_defaults, dim3(2048), dim3(256), 0, stream, taps, (uint64_t)n_pix * iso_count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
 
-    /* persistent grid: as many 256-thread blocks per CU as the path stacks leave room for in LDS
-     * (8 blocks = the CU's 32 wave slots). */
+    /* persistent grid: one 1024-thread block per CU.  Its LDS holds the path stacks and, in what is left of
+     * the CU's 160 KiB, the top K levels of the tree (which take two thirds of all node reads). */
+    const size_t lds_limit = 160u * 1024u;
+    const size_t trace_stack_bytes = ((size_t)stack_levels + 1u) * kTraceThreads * sizeof(uint32_t);
+    uint32_t top_levels = 14;
+    if (const char *tune = getenv("VR_TUNE_TOP_LEVELS")) top_levels = (uint32_t)atoi(tune); /* experiment knob */
+    if (top_levels > 14) top_levels = 14;
+    while (top_levels > 0 && ((((size_t)1 << top_levels) * sizeof(uint32_t)) + trace_stack_bytes > lds_limit ||
+                              ((uint64_t)1 << top_levels) > view.n_slots + 1u))
+        top_levels--;
+    const uint32_t n_top = 1u << top_levels; /* heap positions 0 .. 2^K - 1 = levels 0 .. K-1 (K = 0: the unused slot 0 only) */
+    const size_t trace_lds = (size_t)n_top * sizeof(uint32_t) + trace_stack_bytes;
+    if (trace_lds > lds_limit) return hipErrorInvalidValue;
     const void *fn = any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>;
-    int per_cu = 0;
-    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)kTraceThreads, stack_bytes)) != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    if (const char *tune = getenv("VR_TUNE_BLOCKS_PER_CU")) { /* experiment knob: fewer resident blocks */
-        const int b = atoi(tune);
-        if (b >= 1 && b <= per_cu) per_cu = b;
+    static bool lds_set[2] = { false, false };
+    if (!lds_set[any_tap ? 1 : 0]) {
+        if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit)) != hipSuccess) return e;
+        lds_set[any_tap ? 1 : 0] = true;
     }
-    const uint32_t blocks = (uint32_t)n_cus * (uint32_t)per_cu;
+    const uint32_t blocks = (uint32_t)n_cus;
     const uint64_t frame_pixels = n_pix;
-    void *args[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&max_depth, (void *)&ray_dt, (void *)&ray_pix,
+    void *args[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&ray_dt, (void *)&ray_pix,
                      (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                      (void *)&d_rgb, (void *)&d_stats, (void *)&taps };
 
     if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
-    if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, stack_bytes, stream)) != hipSuccess) return e;
+    if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, trace_lds, stream)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
 #ifdef VR_DIAG

@@ -210,109 +210,95 @@ VR_HD VrHit vr_trace_restart(const VrViewK &v, const VrRay &ray, uint32_t iso, N
  *
  * It walks the PREPARED node array (vr_host_prepare_kdt): produced by a validating walk that
  * guarantees every reachable inner node splits strictly inside its box, which is what lets the
- * loops below run without index, axis or depth checks.
- *
- * Layout of the prepared array: TREELETS.  What bounds this traversal on the GPU is the number of
- * distinct cache lines a wave's gathers touch (L1 misses), and in the reference's breadth-first heap
- * every level of a descent lies in a different line.  So the heap is cut into subtrees of 5 levels
- * (31 nodes) and each subtree is stored in one 128-byte line: a descent touches one line per five
- * levels.  With g = heap index + 1 (root = 1, children 2g and 2g+1) and depth d = 5q + r:
- *   treelet root   g >> r, the k-th node (k = (g >> r) - 32^q) of level 5q
- *   treelet id     (32^q - 1) / 31 + k  =  (g >> r) - C(q),   C(q) = (30 * 32^q + 1) / 31
- *   word address   32 * id + j,   j = (1 << r) | (g & ((1 << r) - 1))   (local heap index 1..31)
- * C obeys C(0) = 1, C(q+1) = 32 C(q) - 1, so the lane keeps (treelet base, j, C) and updates them
- * with a few integer operations per level.  Word format:
+ * loops below run without index, axis or depth checks.  Layout: the reference's heap, 1-based
+ * (the node at heap index i sits at position g = i + 1, children at 2g and 2g + 1, parent g >> 1,
+ * sibling g ^ 1).  Word format:
  *
  *   bits 0-7 min | 8-15 max | 16-23 partition | 24-28 shift (axis * 10) | 31 leaf
  *
- * Stack word per level: the packed bound word (lo or hi) the zoom replaced.  `Stack` provides
- * push(level, word) / pop(level).  `Fetch` provides operator()(word address).
+ * The kernels are bound by VALU issue, so the steps below are written to cost as few vector
+ * instructions as possible: the path stack is addressed by a running pointer instead of a level
+ * index, the reference-defined check count is credited per phase instead of per node, and the exit
+ * plane divisions use a per-ray reciprocal with an FMA correction that reproduces IEEE division
+ * bit for bit (vr_div).
+ *
+ * `Stack` is a cursor over the lane's path stack: push(word) stores at the current level and moves
+ * one level down, pop() moves one level up and returns that level's word, peek_up(k) returns the
+ * word k levels above the cursor without moving, depth() is the current level.
  * ---------------------------------------------------------------------------------------- */
 #define VR_N_LEAF 0x80000000u
 #define VR_MAX_CHECKED (1u << 27) /* safety valve per ray; a 256^3 volume stays far below it */
-#define VR_TREELET_LEVELS 5u
-#define VR_TREELET_WORDS 32u
 
-/* number of 32-word treelets that cover levels 0..max_depth */
-VR_HD uint64_t vr_treelet_count(uint32_t max_depth)
+/* n / d, correctly rounded, from r = RN(1 / d): two FMA residual corrections of n * r.  With r the
+ * correctly rounded reciprocal, the first correction makes the quotient faithful and the second one
+ * lands on the correctly rounded result (Markstein); tests/test_division.py checks 10^8 operand
+ * pairs of the range this path produces against the hardware divide. */
+VR_HD float vr_div(float n, float d, float r)
 {
-    uint64_t n = 0, per_level = 1;
-    for (uint32_t q = 0; q <= max_depth / VR_TREELET_LEVELS; q++) { n += per_level; per_level *= 32u; }
-    return n;
+    const float q0 = n * r;
+    const float e0 = fmaf(-d, q0, n);
+    const float q1 = fmaf(e0, r, q0);
+    const float e1 = fmaf(-d, q1, n);
+    return fmaf(e1, r, q1);
 }
 
-/* word address of heap position g (1-based) at depth d: the closed form of the layout above */
-VR_HD uint64_t vr_treelet_address(uint64_t g, uint32_t d)
+/* Plane.rayIntersect (src/geo.zig:406-426) with the division done by vr_div */
+VR_HD float vr_plane_t_r(float off, float o, float d, float r)
 {
-    const uint32_t q = d / VR_TREELET_LEVELS, r = d % VR_TREELET_LEVELS;
-    uint64_t c = 1; /* C(q) */
-    for (uint32_t i = 0; i < q; i++) c = 32u * c - 1u;
-    const uint64_t id = (g >> r) - c;
-    const uint64_t j = ((uint64_t)1 << r) | (g & (((uint64_t)1 << r) - 1u));
-    return VR_TREELET_WORDS * id + j;
+    const float t = vr_div(off - o, d, r);
+    const float u = t > 0.0f ? t : -1.0f;
+    return fabsf(d) < 1e-8f ? INFINITY : u;
 }
 
 struct VrLane {
     float dx, dy, dz, t;
+    float rx, ry, rz; /* 1 / d per axis, correctly rounded */
     uint32_t cell;    /* packed floor(point), valid while the point is inside the root box */
     uint32_t lo, hi;  /* packed box of the current node */
     uint32_t g;       /* 1-based heap position of the current node */
-    uint32_t depth;
-    uint32_t tb;      /* word address of the current treelet */
-    uint32_t j;       /* local heap index inside the treelet, 1..31 */
-    uint32_t cq;      /* C(depth / 5) */
     uint32_t posmask; /* 0x3ff in the field of every axis the ray travels in the + direction */
     uint32_t checked; /* reference-defined node checks of this ray */
 };
 
-VR_HD void vr_lane_begin(VrLane &L, const VrViewK &v, float dx, float dy, float dz, float t)
+template <class Stack>
+VR_HD void vr_lane_begin(VrLane &L, Stack &stack, const VrViewK &v, float dx, float dy, float dz, float t)
 {
     L.dx = dx; L.dy = dy; L.dz = dz; L.t = t;
+    L.rx = 1.0f / dx; L.ry = 1.0f / dy; L.rz = 1.0f / dz;
     /* inside the root box every coordinate is >= 0, so trunc == floor */
     L.cell = vr_pack10((uint32_t)(v.ox + dx * t), (uint32_t)(v.oy + dy * t), (uint32_t)(v.oz + dz * t));
     L.lo = 0; L.hi = v.root_hi;
-    L.g = 1; L.depth = 0; L.checked = 0;
-    L.tb = 0; L.j = 1; L.cq = 1;
+    L.g = 1; L.checked = 0;
+    stack.reset();
     L.posmask = (dx >= 0.0f ? 0x3ffu : 0u) | (dy >= 0.0f ? (0x3ffu << 10) : 0u) | (dz >= 0.0f ? (0x3ffu << 20) : 0u);
 }
 
 /* Range.containsInclusive on the node's density range, src/geo.zig:196-198 */
 VR_HD bool vr_node_holds(uint32_t n, uint32_t iso) { return (n & 0xffu) <= iso && iso <= ((n >> 8) & 0xffu); }
 
-/* SpaceTracker.zoom (src/SlimKDT.zig:90-103) on an inner node whose range holds the iso value */
-template <class Stack>
-VR_HD void vr_lane_zoom(VrLane &L, uint32_t n, Stack &stack)
+/* Descends from the current node while the node's density range holds the iso value
+ * (src/raytrace.zig:161-194, zoom: src/SlimKDT.zig:90-103).  Returns true on a hit (a leaf whose
+ * range holds the iso value), false when the node at L.g excludes it (-> MOVE). */
+template <class Fetch, class Stack>
+VR_HD bool vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stack &stack)
 {
-    const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
-    const bool left = ((L.cell >> sh) & 0xffu) < part;
-    uint32_t side = left ? L.hi : L.lo;
-    stack.push(L.depth, side);
-    side = (side & ~(0xffu << sh)) | (part << sh); /* partition is strictly inside the box: min/max of geo.zig:256-275 pick it */
-    L.hi = left ? side : L.hi;
-    L.lo = left ? L.lo : side;
-    const uint32_t b = left ? 0u : 1u;
-    L.g = 2u * L.g + b;
-    L.depth++;
-    /* treelet bookkeeping: a child of the treelet's bottom level is the root of a new treelet */
-    const uint32_t j2 = 2u * L.j + b;
-    const bool cross = j2 >= VR_TREELET_WORDS;
-    const uint32_t cn = (L.cq << 5) - 1u;
-    L.cq = cross ? cn : L.cq;
-    L.tb = cross ? ((L.g - cn) << 5) : L.tb;
-    L.j = cross ? 1u : j2;
-}
-
-/* recomputes (tb, j, cq) from (g, depth) */
-VR_HD void vr_lane_locate(VrLane &L)
-{
-    const uint32_t q = (L.depth * 13u) >> 6; /* depth / 5 for depth < 64 */
-    const uint32_t r = L.depth - 5u * q;
-    const uint32_t sh = 5u * q;
-    const uint32_t c = (1u << sh) - (0x42108421u & ((1u << sh) - 1u)); /* C(q) = 32^q - (32^q - 1) / 31 */
-    const uint32_t root = L.g >> r;
-    L.cq = c;
-    L.tb = (root - c) << 5;
-    L.j = L.g - (root << r) + (1u << r);
+    const uint32_t d0 = stack.depth();
+    bool holds;
+    for (;;) {
+        const uint32_t n = fetch(L.g);
+        holds = vr_node_holds(n, iso);
+        if (!holds || (n & VR_N_LEAF)) break;
+        const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
+        const bool left = ((L.cell >> sh) & 0xffu) < part;
+        uint32_t side = left ? L.hi : L.lo;
+        stack.push(side);
+        side = (side & ~(0xffu << sh)) | (part << sh); /* partition is strictly inside the box: min/max of geo.zig:256-275 pick it */
+        L.hi = left ? side : L.hi;
+        L.lo = left ? L.lo : side;
+        L.g = 2u * L.g + (left ? 0u : 1u);
+    }
+    L.checked += stack.depth() - d0 + 1u; /* one check per node visited, src/raytrace.zig:162 */
+    return holds;
 }
 
 /* MOVE (src/raytrace.zig:199-205) + escape help (:233-242).  Returns false when the new point is
@@ -321,9 +307,9 @@ VR_HD bool vr_lane_move(VrLane &L, const VrViewK &v, uint32_t &escapes)
 {
     const uint32_t ex = (L.hi & L.posmask) | (L.lo & ~L.posmask); /* exit plane per axis: max if d >= 0 else min */
     float t = INFINITY;
-    t = fminf(t, vr_plane_t((float)(ex & 0xffu), v.ox, L.dx));
-    t = fminf(t, vr_plane_t((float)((ex >> 10) & 0xffu), v.oy, L.dy));
-    t = fminf(t, vr_plane_t((float)((ex >> 20) & 0xffu), v.oz, L.dz));
+    t = fminf(t, vr_plane_t_r((float)(ex & 0xffu), v.ox, L.dx, L.rx));
+    t = fminf(t, vr_plane_t_r((float)((ex >> 10) & 0xffu), v.oy, L.dy, L.ry));
+    t = fminf(t, vr_plane_t_r((float)((ex >> 20) & 0xffu), v.oz, L.dz, L.rz));
     t += 0.0001f;
     float i = 0.0f;
     bool in_root;
@@ -352,50 +338,35 @@ VR_HD bool vr_lane_move(VrLane &L, const VrViewK &v, uint32_t &escapes)
 template <class Stack>
 VR_HD void vr_lane_pop(VrLane &L, Stack &stack)
 {
-    uint32_t next = stack.pop(L.depth - 1u);
+    const uint32_t cg = L.cell | VR_F_GUARD, cp = L.cell + VR_F_ONES;
+    uint32_t next = stack.peek_up(1);
     for (;;) {
-        L.depth--; /* level of the parent A */
-        const uint32_t word = next; /* A's bound word that the zoom into C replaced */
-        next = stack.pop(L.depth > 0u ? L.depth - 1u : 0u);
-        const bool left = (L.g & 1u) == 0u;       /* even position = left child: the zoom had cut hi */
-        const uint32_t cut = left ? L.hi : L.lo;  /* C's cut side */
-        const uint32_t keep = left ? L.lo : L.hi; /* the side C shares with A */
-        const uint32_t a_lo = left ? keep : word, a_hi = left ? word : keep;
-        if (vr_box_contains_cell(a_lo, a_hi, L.cell)) {
+        const uint32_t word = next;        /* A's bound word that the zoom into C replaced */
+        stack.up();                        /* cursor at the level of the parent A */
+        next = stack.peek_up(1);           /* harmless when already at the root: that word is never used */
+        const bool left = (L.g & 1u) == 0u; /* even position = left child: the zoom had cut hi */
+        const uint32_t c_lo = L.lo, c_hi = L.hi;
+        L.hi = left ? word : c_hi;
+        L.lo = left ? c_lo : word;
+        const uint32_t a = cg - L.lo, b = (L.hi | VR_F_GUARD) - cp; /* vr_box_contains_cell, shared parts hoisted */
+        if (((a & b) & VR_F_GUARD) == VR_F_GUARD) {
+            const uint32_t cut = left ? c_hi : c_lo;   /* C's cut side */
+            const uint32_t keep = left ? c_lo : c_hi;  /* the side C shares with A */
             const uint32_t diff = word ^ cut;
             const uint32_t fm = (diff & 0x3ffu) ? 0x3ffu : ((diff & 0xffc00u) ? 0xffc00u : 0x3ff00000u);
             const uint32_t other = (keep & ~fm) | (cut & fm); /* sibling's new bound on the side it cuts */
-            stack.push(L.depth, keep);
-            L.lo = left ? other : a_lo;
-            L.hi = left ? a_hi : other;
+            stack.push(keep);
+            L.lo = left ? other : L.lo;
+            L.hi = left ? L.hi : other;
             L.g ^= 1u;
-            L.depth++;
-            L.checked += L.depth;
-            vr_lane_locate(L);
+            L.checked += stack.depth();
             return;
         }
-        L.lo = a_lo;
-        L.hi = a_hi;
         L.g >>= 1;
     }
 }
 
 VR_HD uint32_t vr_unpack_cell(uint32_t c10) { return (c10 & 0xffu) | (((c10 >> 10) & 0xffu) << 8) | (((c10 >> 20) & 0xffu) << 16); }
-
-/* Descends from the current node while the node's density range holds the iso value
- * (src/raytrace.zig:161-194).  Returns true on a hit (a leaf whose range holds the iso value), false
- * when the node at L.g excludes it (-> MOVE). */
-template <class Fetch, class Stack>
-VR_HD bool vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stack &stack)
-{
-    for (;;) {
-        const uint32_t n = fetch(L.tb + L.j);
-        L.checked++;
-        const bool holds = vr_node_holds(n, iso);
-        if (!holds || (n & VR_N_LEAF)) return holds;
-        vr_lane_zoom(L, n, stack);
-    }
-}
 
 /* one ray from entry to hit or miss; `fetch` reads the PREPARED node array */
 template <class Fetch, class Stack>
@@ -405,7 +376,7 @@ VR_HD VrHit vr_trace_resume(const VrViewK &v, const VrRay &ray, uint32_t iso, co
     h.t = 0.0f; h.flag = 2u; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
     if (ray.oob) return h;
     VrLane L;
-    vr_lane_begin(L, v, ray.dx, ray.dy, ray.dz, ray.t);
+    vr_lane_begin(L, stack, v, ray.dx, ray.dy, ray.dz, ray.t);
     h.flag = 0u;
     for (;;) {
         if (vr_lane_descend(L, iso, fetch, stack)) {
