@@ -140,6 +140,12 @@ void vr_main_camera(const uint32_t res[3], const float pos[3], float forw_out[3]
 
 void vr_free(void *p);
 
+/* Output side of the reference driver (src/main.zig:116,137 writes renders/out_iso{d}.png through
+ * zigimg): an 8-bit RGB PNG (stored deflate blocks, readable by any PNG decoder) or a binary PPM of
+ * a finished width*height*3 frame. */
+int vr_write_png_rgb24(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb24);
+int vr_write_ppm_rgb24(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb24);
+
 /* ---- device contexts -------------------------------------------------------------------- */
 
 /* One context per device.  Fails with VR_ENODEVICE when no HIP device is present or the device is

@@ -25,7 +25,8 @@ struct HostStack {
 } // namespace
 
 /* variant 1 walks the reference's SlimNode array with the literal restart loop; any other variant walks
- * the PREPARED array (vr_host_prepare_kdt of the product library) with the resume traversal */
+ * the PREPARED array (vr_host_prepare_kdt of the product library) with the resume traversal; variant
+ * 100 + k bounds every descend / pop phase to k levels, as the persistent kernel does */
 extern "C" int vr_emu_render(int variant, const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3],
                              const float src[3], const float forw[3], const float up[3], uint32_t width,
                              uint32_t height, float viewport_width, uint32_t iso, uint8_t *rgb, uint32_t *cell_flag,
@@ -54,7 +55,7 @@ extern "C" int vr_emu_render(int variant, const uint32_t *nodes, uint64_t n_slot
                 h = vr_trace_restart(k, ray, iso, HostFetch{ nodes });
             } else {
                 HostStack st;
-                h = vr_trace_resume(k, ray, iso, HostFetch{ nodes }, st);
+                h = vr_trace_resume(k, ray, iso, HostFetch{ nodes }, st, variant >= 100 ? (uint32_t)(variant - 100) : 64u);
             }
             uint64_t pix = (uint64_t)yi * width + xi;
             uint8_t g = h.flag == 1u ? vr_shade(h.t) : 0;

@@ -243,3 +243,21 @@ def test_build_on_context_and_download(oracle, c60_vox, c60_tree):
         assert bs.number_of_nodes == st.number_of_nodes and bs.layer_count == st.layer_count
         got, grd = r.download_kdt()
         assert (grd == rd).all() and len(got) == len(nodes) and (got == nodes).all()
+
+
+def test_vr_bench_driver_reproduces_reference_renders(tmp_path, golden_gray):
+    """The C++ driver with the shape of the reference's main: writes renders/out_iso{d}.png and prints the
+    comparison table; its files decode to the reference's own images."""
+    import os
+    import subprocess
+    PIL = pytest.importorskip("PIL.Image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "volumerenderer_amd", "vr_bench")
+    out = subprocess.run([exe, "--volume", os.path.join(root, "tests", "data", "C60.vol"), "--size", "512", "--iso",
+                          "97:103", "--heuristics", "center", "--out", str(tmp_path)], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "(ms/frame)" in out.stdout and "nodes: 500093" in out.stdout and "layers: 18" in out.stdout
+    for iso in range(97, 103):
+        img = np.asarray(PIL.open(tmp_path / ("out_iso%d.png" % iso)).convert("RGB"))
+        assert (img[..., 0] == golden_gray[iso]).all() and (img[..., 1] == img[..., 0]).all()

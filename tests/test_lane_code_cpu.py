@@ -7,7 +7,7 @@ import pytest
 from helpers import assert_same_render, emu_render, random_volume
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 3, 101, 103, 106])
 @pytest.mark.parametrize("iso", [0, 1, 57, 100, 200, 255])
 def test_c60_lane_code(oracle, emu_lib, c60_vox, c60_tree, variant, iso):
     nodes, rd, _ = c60_tree
@@ -52,7 +52,7 @@ def test_odd_cameras_and_small_volumes(oracle, emu_lib):
             pos, forw, up = oracle.main_camera(shape, pos)
             for iso in (0, 40, 200):
                 ref = oracle.render(nodes, rd, pos, forw, up, 64, 48, 0.5, iso)
-                for variant in (1, 3):
+                for variant in (1, 3, 102, 105):
                     got = emu_render(emu_lib, variant, nodes, rd, pos, forw, up, 64, 48, 0.5, iso)
                     assert_same_render(got, ref, "%s %s iso %d v%d" % (shape, pos, iso, variant))
 

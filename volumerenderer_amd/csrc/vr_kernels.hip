@@ -35,6 +35,14 @@ constexpr uint32_t kTopNodes = 4095;           /* heap levels 0..11, 16 KiB of L
 #define VR_REFILL_MIN 16
 #endif
 constexpr uint32_t kRefillMin = VR_REFILL_MIN; /* refill a wave once this many lanes idle */
+#ifndef VR_DESCEND_TRIPS
+#define VR_DESCEND_TRIPS 8
+#endif
+#ifndef VR_POP_TRIPS
+#define VR_POP_TRIPS 6
+#endif
+/* levels a lane may descend / pop per round before the wave moves on; unfinished lanes continue next round */
+constexpr uint32_t kDescendTrips = VR_DESCEND_TRIPS, kPopTrips = VR_POP_TRIPS;
 
 struct GlobalFetch {
     const uint32_t *nodes;
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void vr_k_render(VrViewK v, const uint32_t *__
             h = vr_trace_restart(v, ray, iso, TopLdsFetch{ nodes, s_top });
         } else {
             LdsStack<256u> st(s_dyn);
-            h = vr_trace_resume(v, ray, iso, GlobalFetch{ nodes }, st);
+            h = vr_trace_resume(v, ray, iso, GlobalFetch{ nodes }, st, 64u);
         }
         const uint64_t pix = ((uint64_t)blockIdx.y * n_rows + yr) * v.width + xi;
         const uint8_t g = h.flag == VR_FLAG_HIT ? vr_shade(h.t) : (uint8_t)0;
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
 
         VrLane L;
         uint32_t pix = 0;
-        bool alive = false, exhausted = false;
+        bool alive = false, exhausted = false, popping = false;
         unsigned long long a_checked = 0;
         uint32_t a_hit = 0, a_miss = 0, a_moves = 0, a_esc = 0, a_err = 0;
 
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
                     pix = ray_pix[mine];
                     vr_lane_begin(L, stack, v, r.x, r.y, r.z, r.w);
                     alive = true;
+                    popping = false;
                 }
                 exhausted = base + n_idle >= n_active;
                 DIAG_ADD(12, 1);
@@ -358,54 +367,35 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
             uint32_t d_trips = 0, d_pops = 0;
 #endif
 
-            bool holds = false;
             if (alive) {
-                /* ---- descend while the node's density range holds the iso value ---- */
+                uint32_t go = VR_GO_MORE;
+                if (!popping) {
+                    /* ---- descend while the node's density range holds the iso value (bounded) ---- */
 #ifdef VR_DIAG
-                d_trips = stack.depth();
+                    d_trips = stack.depth();
 #endif
-                holds = vr_lane_descend(L, iso, fetch, stack);
+                    go = vr_lane_descend(L, iso, fetch, stack, kDescendTrips);
 #ifdef VR_DIAG
-                d_trips = stack.depth() + 1u - d_trips; /* levels visited */
-                d_pops = stack.depth();
+                    d_trips = stack.depth() - d_trips + (go != VR_GO_MORE ? 1u : 0u);
 #endif
-            }
-#ifdef VR_DIAG
-            { DIAG_T(d_t2); DIAG_ADD(2, d_t2 - d_t1); } /* wave-level: the whole descend phase */
-            bool d_did_move = false;
-#endif
-            if (alive) {
-                if (holds) { /* hit: shade and store (src/raytrace.zig:56-61) */
+                }
+                if (go == VR_GO_HIT) { /* shade and store (src/raytrace.zig:56-61) */
                     const uint8_t g = vr_shade(L.t);
-#ifdef VR_TUNE_NO_STORE
-                    if (g == 1)
-#endif
-                    {
-                        frame[(uint64_t)pix * 3u + 0u] = g;
-                        frame[(uint64_t)pix * 3u + 1u] = g;
-                        frame[(uint64_t)pix * 3u + 2u] = g;
-                    }
+                    frame[(uint64_t)pix * 3u + 0u] = g;
+                    frame[(uint64_t)pix * 3u + 1u] = g;
+                    frame[(uint64_t)pix * 3u + 2u] = g;
                     a_hit++;
                     alive = false;
                     if (TAPS) {
                         if (taps.cell_flag) taps.cell_flag[tap_base + pix] = vr_unpack_cell(L.cell) | (VR_FLAG_HIT << 24);
                         if (taps.node) taps.node[tap_base + pix] = L.g - 1u;
                     }
-                } else {
+                } else if (go == VR_GO_EXCLUDED) {
                     a_moves++;
-#ifdef VR_DIAG
-                    d_did_move = true;
-#endif
                     bool in_root = vr_lane_move(L, v, a_esc);
                     if (L.checked > VR_MAX_CHECKED) { in_root = false; a_err++; }
-#ifdef VR_DIAG
-                    if (__builtin_amdgcn_readfirstlane(1)) { DIAG_T(d_tm); d_acc[3] += d_tm; }
-#endif
                     if (in_root) {
-                        vr_lane_pop(L, stack);
-#ifdef VR_DIAG
-                        d_pops = d_pops + 1u - stack.depth(); /* levels popped */
-#endif
+                        popping = true;
                     } else { /* left the volume: a miss, the pixel stays black (src/raytrace.zig:66-68) */
                         a_miss++;
                         alive = false;
@@ -414,6 +404,16 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
                             if (taps.node) taps.node[tap_base + pix] = 0u;
                         }
                     }
+                }
+                if (alive && popping) {
+                    /* ---- pop to the lowest ancestor that holds the new point (bounded) ---- */
+#ifdef VR_DIAG
+                    d_pops = stack.depth();
+#endif
+                    popping = !vr_lane_pop(L, stack, kPopTrips);
+#ifdef VR_DIAG
+                    d_pops = d_pops + (popping ? 0u : 1u) - stack.depth();
+#endif
                 }
                 if (!alive) {
                     a_checked += L.checked;
@@ -427,8 +427,6 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
             {
                 DIAG_T(d_t3);
                 DIAG_ADD(1, d_t3 - d_t1); /* everything after the refill */
-                if (__ballot(d_did_move)) { DIAG_ADD(4, d_t3); DIAG_ADD(14, 1); } /* d_acc[4]-d_acc[3] = pop phase + tail */
-                if (!alive) d_pops = 0;
                 const uint32_t m1 = wave_max(d_trips), s1 = wave_sum(d_trips), m2 = wave_max(d_pops), s2 = wave_sum(d_pops);
                 DIAG_ADD(6, m1); DIAG_ADD(7, s1); DIAG_ADD(8, m2); DIAG_ADD(9, s2);
             }

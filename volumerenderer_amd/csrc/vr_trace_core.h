@@ -276,18 +276,24 @@ VR_HD void vr_lane_begin(VrLane &L, Stack &stack, const VrViewK &v, float dx, fl
 /* Range.containsInclusive on the node's density range, src/geo.zig:196-198 */
 VR_HD bool vr_node_holds(uint32_t n, uint32_t iso) { return (n & 0xffu) <= iso && iso <= ((n >> 8) & 0xffu); }
 
+/* Outcome of a bounded phase of a lane */
+#define VR_GO_HIT 0u      /* reached a leaf whose range holds the iso value                     */
+#define VR_GO_EXCLUDED 1u /* the node at L.g excludes the iso value: MOVE next                   */
+#define VR_GO_MORE 2u     /* trip budget used up: the same phase continues in the next round     */
+
 /* Descends from the current node while the node's density range holds the iso value
- * (src/raytrace.zig:161-194, zoom: src/SlimKDT.zig:90-103).  Returns true on a hit (a leaf whose
- * range holds the iso value), false when the node at L.g excludes it (-> MOVE). */
+ * (src/raytrace.zig:161-194, zoom: src/SlimKDT.zig:90-103), at most `max_trips` levels per call.
+ * A wave runs a loop as long as its slowest lane; bounding the trips and letting the few long
+ * descents continue in the next round keeps the lanes of a wave busy. */
 template <class Fetch, class Stack>
-VR_HD bool vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stack &stack)
+VR_HD uint32_t vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stack &stack, uint32_t max_trips)
 {
     const uint32_t d0 = stack.depth();
-    bool holds;
-    for (;;) {
+    uint32_t out = VR_GO_MORE;
+    for (uint32_t trip = 0; trip < max_trips; trip++) {
         const uint32_t n = fetch(L.g);
-        holds = vr_node_holds(n, iso);
-        if (!holds || (n & VR_N_LEAF)) break;
+        const bool holds = vr_node_holds(n, iso);
+        if (!holds || (n & VR_N_LEAF)) { out = holds ? VR_GO_HIT : VR_GO_EXCLUDED; break; }
         const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
         const bool left = ((L.cell >> sh) & 0xffu) < part;
         uint32_t side = left ? L.hi : L.lo;
@@ -297,8 +303,9 @@ VR_HD bool vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stack &s
         L.lo = left ? L.lo : side;
         L.g = 2u * L.g + (left ? 0u : 1u);
     }
-    L.checked += stack.depth() - d0 + 1u; /* one check per node visited, src/raytrace.zig:162 */
-    return holds;
+    /* one check per node tested (src/raytrace.zig:162): every level passed, plus the node that ended the descent */
+    L.checked += stack.depth() - d0 + (out != VR_GO_MORE ? 1u : 0u);
+    return out;
 }
 
 /* MOVE (src/raytrace.zig:199-205) + escape help (:233-242).  Returns false when the new point is
@@ -334,16 +341,18 @@ VR_HD bool vr_lane_move(VrLane &L, const VrViewK &v, uint32_t &escapes)
  * field is the one where A's and C's cut bound differ, and the partition is C's value there.)
  * Credits the depth(A)+1 node checks the reference spends on root .. A.  The stack word of the next
  * level up is requested before the current one is examined, so its latency hides behind the test.
+ * At most `max_trips` levels per call; returns true when the sibling was entered, false when the
+ * budget ran out first (call again).
  * Precondition: the point is inside the root box and outside the current box (so depth >= 1). */
 template <class Stack>
-VR_HD void vr_lane_pop(VrLane &L, Stack &stack)
+VR_HD bool vr_lane_pop(VrLane &L, Stack &stack, uint32_t max_trips)
 {
     const uint32_t cg = L.cell | VR_F_GUARD, cp = L.cell + VR_F_ONES;
     uint32_t next = stack.peek_up(1);
-    for (;;) {
+    for (uint32_t trip = 0; trip < max_trips; trip++) {
         const uint32_t word = next;        /* A's bound word that the zoom into C replaced */
         stack.up();                        /* cursor at the level of the parent A */
-        next = stack.peek_up(1);           /* harmless when already at the root: that word is never used */
+        next = stack.peek_up(1);           /* at the root this reads the spare row: never used */
         const bool left = (L.g & 1u) == 0u; /* even position = left child: the zoom had cut hi */
         const uint32_t c_lo = L.lo, c_hi = L.hi;
         L.hi = left ? word : c_hi;
@@ -360,17 +369,19 @@ VR_HD void vr_lane_pop(VrLane &L, Stack &stack)
             L.hi = left ? L.hi : other;
             L.g ^= 1u;
             L.checked += stack.depth();
-            return;
+            return true;
         }
         L.g >>= 1;
     }
+    return false;
 }
 
 VR_HD uint32_t vr_unpack_cell(uint32_t c10) { return (c10 & 0xffu) | (((c10 >> 10) & 0xffu) << 8) | (((c10 >> 20) & 0xffu) << 16); }
 
 /* one ray from entry to hit or miss; `fetch` reads the PREPARED node array */
 template <class Fetch, class Stack>
-VR_HD VrHit vr_trace_resume(const VrViewK &v, const VrRay &ray, uint32_t iso, const Fetch &fetch, Stack &stack)
+VR_HD VrHit vr_trace_resume(const VrViewK &v, const VrRay &ray, uint32_t iso, const Fetch &fetch, Stack &stack,
+                            uint32_t max_trips)
 {
     VrHit h;
     h.t = 0.0f; h.flag = 2u; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
@@ -379,7 +390,9 @@ VR_HD VrHit vr_trace_resume(const VrViewK &v, const VrRay &ray, uint32_t iso, co
     vr_lane_begin(L, stack, v, ray.dx, ray.dy, ray.dz, ray.t);
     h.flag = 0u;
     for (;;) {
-        if (vr_lane_descend(L, iso, fetch, stack)) {
+        const uint32_t go = vr_lane_descend(L, iso, fetch, stack, max_trips);
+        if (go == VR_GO_MORE) continue;
+        if (go == VR_GO_HIT) {
             /* a leaf cell whose range holds the iso value: the hit (src/raytrace.zig:178-187) */
             h.flag = 1u; h.node = L.g - 1u; h.cell = vr_unpack_cell(L.cell);
             break;
@@ -387,7 +400,7 @@ VR_HD VrHit vr_trace_resume(const VrViewK &v, const VrRay &ray, uint32_t iso, co
         h.moves++;
         if (L.checked > VR_MAX_CHECKED) { h.error = 1; break; }
         if (!vr_lane_move(L, v, h.escapes)) break;
-        vr_lane_pop(L, stack);
+        while (!vr_lane_pop(L, stack, max_trips)) {}
     }
     h.t = L.t;
     h.checked = L.checked;
