@@ -236,13 +236,42 @@ def test_error_paths_on_device(c60_tree):
 
 
 def test_build_on_context_and_download(oracle, c60_vox, c60_tree):
+    """vr_build_kdt: the centre-split tree is built on the GPU; the downloaded array is the oracle's, word for
+    word (zeros in unoccupied slots included); span heuristics go through the host builder."""
     nodes, rd, st = c60_tree
     with vr.Renderer(0) as r:
         r.upload_volume(vr.Data(c60_vox))
         bs = r.build_kdt("AlwaysCenter")
         assert bs.number_of_nodes == st.number_of_nodes and bs.layer_count == st.layer_count
+        assert bs.non_center_partition_count == 0
         got, grd = r.download_kdt()
         assert (grd == rd).all() and len(got) == len(nodes) and (got == nodes).all()
+        # and the tree renders like the uploaded one
+        pos, forw, up = oracle.main_camera(c60_vox.shape)
+        ref = oracle.render(nodes, rd, pos, forw, up, 200, 200, 2.0, 100)
+        assert_same_render(_gpu(r, pos, forw, up, 200, 200, 2.0, 100), ref, "GPU-built tree")
+        bs = r.build_kdt("FlexibleFirst5")
+        k = vr.SlimKDT.newHeursiticPartition(vr.Data(c60_vox), "FlexibleFirst5")
+        got, _ = r.download_kdt()
+        assert bs.non_center_partition_count == k.build.non_center_partition_count and (got == k.nodes).all()
+
+
+def test_gpu_tree_build_matches_host_builder(skull_vox, skull_tree):
+    rng = np.random.default_rng(21)
+    cases = [skull_vox, vr.datasets.bonsai_standin(), random_volume(rng, (2, 2, 2), "noise"),
+             random_volume(rng, (3, 2, 7), "noise"), random_volume(rng, (17, 33, 9), "smooth"),
+             random_volume(rng, (64, 5, 130), "sparse"), random_volume(rng, (256, 2, 2), "noise")]
+    for vox in cases:
+        k = vr.SlimKDT.newHeursiticPartition(vr.Data(vox), "AlwaysCenter")
+        with vr.Renderer(0) as r:
+            r.upload_volume(vr.Data(vox))
+            bs = r.build_kdt("AlwaysCenter")
+            got, grd = r.download_kdt()
+        assert bs.layer_count == k.build.layer_count and bs.number_of_nodes == k.build.number_of_nodes, vox.shape
+        n = min(len(got), len(k.nodes))
+        assert (got[:n] == k.nodes[:n]).all() and not got[n:].any() and not k.nodes[n:].any(), vox.shape
+        assert (grd == k.root_dim).all()
+    assert (skull_tree[0] == vr.SlimKDT.newHeursiticPartition(vr.Data(skull_vox)).nodes[: len(skull_tree[0])]).all()
 
 
 def test_vr_bench_driver_reproduces_reference_renders(tmp_path, golden_gray):

@@ -12,3 +12,4 @@ from .data import Data  # noqa: F401
 from .slimkdt import SlimKDT  # noqa: F401
 from . import raytrace  # noqa: F401
 from .raytrace import Image, Renderer, main_camera  # noqa: F401
+from . import datasets, sharding  # noqa: F401,E402

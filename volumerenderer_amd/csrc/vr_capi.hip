@@ -182,15 +182,42 @@ int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint
 int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
 {
     if (!c) return VR_EARG;
-    if (!c->h_vox) return VR_ESTATE;
-    uint32_t *nodes = nullptr;
-    uint64_t n_slots = 0;
-    uint8_t rd[3];
-    int rc = vr_host_build_kdt(c->h_vox, c->res, heuristic, 0, &nodes, &n_slots, rd, stats_out);
-    if (rc != VR_OK) return rc;
-    rc = vr_upload_kdt(c, nodes, n_slots, rd);
-    vr_free(nodes);
-    return rc;
+    if (!c->h_vox || !c->d_vox) return VR_ESTATE;
+    if (heuristic < 0 || heuristic >= VR_H_COUNT) return VR_EARG;
+    if (heuristic != VR_H_ALWAYS_CENTER) {
+        /* span heuristics: host builder, then the ordinary upload path */
+        uint32_t *nodes = nullptr;
+        uint64_t n_slots = 0;
+        uint8_t rd[3];
+        int rc = vr_host_build_kdt(c->h_vox, c->res, heuristic, 0, &nodes, &n_slots, rd, stats_out);
+        if (rc != VR_OK) return rc;
+        rc = vr_upload_kdt(c, nodes, n_slots, rd);
+        vr_free(nodes);
+        return rc;
+    }
+    /* centre split: built on the device, valid by construction (no host walk, no PCIe traffic) */
+    const uint32_t depth = vr_center_tree_depth(c->res[0], c->res[1], c->res[2]);
+    const uint64_t n_slots = (uint64_t)1 << (depth + 1);
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
+    if (e == hipSuccess && c->d_prepared) { e = hipFree(c->d_prepared); c->d_prepared = nullptr; }
+    c->n_slots = 0;
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_nodes, n_slots * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_prepared, (n_slots + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = vr_launch_build_center(c->stream, c->d_vox, c->res[0], c->res[1], c->res[2], depth, c->d_nodes, c->d_prepared);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
+    c->n_slots = n_slots;
+    c->max_depth = depth;
+    for (int a = 0; a < 3; a++) c->root_dim[a] = (uint8_t)(c->res[a] - 1u);
+    if (stats_out) {
+        /* a full binary tree over the cells: 2 * cells - 1 nodes; every partition is the centre one */
+        const uint64_t cells = (uint64_t)(c->res[0] - 1u) * (c->res[1] - 1u) * (c->res[2] - 1u);
+        stats_out->non_center_partition_count = 0;
+        stats_out->layer_count = depth;
+        stats_out->number_of_nodes = 2 * cells - 1;
+    }
+    return VR_OK;
 }
 
 int vr_download_kdt(vr_ctx *c, uint32_t *nodes_out, uint64_t cap_slots, uint64_t *n_slots_out, uint8_t root_dim_out[3])
