@@ -27,6 +27,7 @@ struct vr_ctx {
     /* tree */
     uint32_t *d_nodes = nullptr;      /* SlimKDT.nodes as the reference lays them out          */
     uint32_t *d_prepared = nullptr;   /* the validated, flattened form the fast kernels walk   */
+    void *d_prepared_raw = nullptr;   /* the allocation d_prepared lies in                     */
     uint64_t n_slots = 0;
     uint32_t max_depth = 0;
     uint8_t root_dim[3] = { 0, 0, 0 };
@@ -57,6 +58,34 @@ int ensure(void **p, size_t *cap, size_t need)
     VR_HIP(hipMalloc(p, need));
     *cap = need;
     return VR_OK;
+}
+
+/* Device array that does not cross a 4 GiB address boundary (the persistent kernel adds 32-bit offsets to
+ * the low word of its address).  Always possible up to 2 GiB; beyond that the array is taken as it comes and
+ * the launcher falls back to a kernel with 64-bit addressing if it does cross. */
+hipError_t alloc_within_4g(size_t bytes, void **raw, uint32_t **use)
+{
+    hipError_t e = hipMalloc(raw, bytes);
+    if (e != hipSuccess) return e;
+    uintptr_t p = (uintptr_t)*raw;
+    if ((p >> 32) == ((p + bytes - 1) >> 32) || bytes > ((size_t)2 << 30)) {
+        *use = (uint32_t *)p;
+        return hipSuccess;
+    }
+    (void)hipFree(*raw);
+    *raw = nullptr;
+    if ((e = hipMalloc(raw, 2 * bytes)) != hipSuccess) return e;
+    p = (uintptr_t)*raw;
+    const uintptr_t boundary = ((p >> 32) + 1) << 32; /* if [p, p + bytes) crosses it, [boundary, boundary + bytes) fits */
+    *use = (uint32_t *)((p >> 32) == ((p + bytes - 1) >> 32) ? p : boundary);
+    return hipSuccess;
+}
+
+void free_prepared(vr_ctx *c)
+{
+    if (c->d_prepared_raw) (void)hipFree(c->d_prepared_raw);
+    c->d_prepared_raw = nullptr;
+    c->d_prepared = nullptr;
 }
 
 /* the per-image constants of renderImage, src/raytrace.zig:22-24,38; computed in strict f32 */
@@ -123,7 +152,7 @@ void vr_ctx_destroy(vr_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_vox) (void)hipFree(c->d_vox);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
-    if (c->d_prepared) (void)hipFree(c->d_prepared);
+    free_prepared(c);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     if (c->d_stats) (void)hipFree(c->d_stats);
@@ -165,10 +194,10 @@ int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint
     if (rc != VR_OK) { std::free(prepared); return rc; }
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
-    if (e == hipSuccess && c->d_prepared) { e = hipFree(c->d_prepared); c->d_prepared = nullptr; }
+    free_prepared(c);
     c->n_slots = 0;
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_nodes, n_slots * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_prepared, prep_words * sizeof(uint32_t));
+    if (e == hipSuccess) e = alloc_within_4g(prep_words * sizeof(uint32_t), &c->d_prepared_raw, &c->d_prepared);
     if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_prepared, prepared, prep_words * sizeof(uint32_t), hipMemcpyHostToDevice);
     std::free(prepared);
@@ -200,10 +229,10 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
     const uint64_t n_slots = (uint64_t)1 << (depth + 1);
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
-    if (e == hipSuccess && c->d_prepared) { e = hipFree(c->d_prepared); c->d_prepared = nullptr; }
+    free_prepared(c);
     c->n_slots = 0;
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_nodes, n_slots * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_prepared, (n_slots + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = alloc_within_4g((n_slots + 1) * sizeof(uint32_t), &c->d_prepared_raw, &c->d_prepared);
     if (e == hipSuccess) e = vr_launch_build_center(c->stream, c->d_vox, c->res[0], c->res[1], c->res[2], depth, c->d_nodes, c->d_prepared);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return VR_EHIP_BASE - (int)e;

@@ -36,7 +36,7 @@ constexpr uint32_t kTopNodes = 4095;           /* heap levels 0..11, 16 KiB of L
 #endif
 constexpr uint32_t kRefillMin = VR_REFILL_MIN; /* refill a wave once this many lanes idle */
 #ifndef VR_DESCEND_TRIPS
-#define VR_DESCEND_TRIPS 8
+#define VR_DESCEND_TRIPS 6
 #endif
 #ifndef VR_POP_TRIPS
 #define VR_POP_TRIPS 6
@@ -67,35 +67,79 @@ struct TopLdsFetch {
     }
 };
 
-/* path stack cursor: one 32-bit word per level, one column per thread of the block, [level][thread],
- * preceded by one spare row so that looking one level above the root stays inside the allocation */
+/* Path stack cursor.  The stacks sit at the start of the block's dynamic LDS as [row][thread] words: row 0
+ * is a spare (looking one level above the root stays inside the allocation), row d + 1 holds the word pushed
+ * at depth d.  The cursor is the LDS byte address of row `depth` in this thread's column. */
 template <uint32_t STRIDE>
 struct LdsStack {
-    uint32_t *base; /* level 0 of this thread's column */
-    uint32_t *sp;
-    __device__ __forceinline__ explicit LdsStack(uint32_t *dyn) : base(dyn + STRIDE + threadIdx.x), sp(base) {}
-    __device__ __forceinline__ void reset() { sp = base; }
-    __device__ __forceinline__ void push(uint32_t word) { *sp = word; sp += STRIDE; }
-    __device__ __forceinline__ void up() { sp -= STRIDE; }
-    __device__ __forceinline__ uint32_t peek_up(uint32_t k) const { return *(sp - k * STRIDE); }
-    __device__ __forceinline__ uint32_t depth() const { return (uint32_t)(sp - base) / STRIDE; }
-};
-
-/* heap positions below n_top come from the LDS copy of the top tree levels, deeper ones from global memory.
- * The LDS read is unconditional (clamped index) and the global read sits behind a branch that the wave
- * skips when no lane is that deep: written as a select of two pointers the compiler turns the pair into one
- * flat load, which sends the LDS hits through the vector memory path as well. */
-struct TopFetch {
-    const uint32_t *nodes;
-    uint32_t n_top; /* > 0 */
-    __device__ __forceinline__ uint32_t operator()(uint32_t g) const
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    static constexpr uint32_t kRowBytes = STRIDE * 4u;
+    uint32_t origin; /* LDS byte address of row 0 of this thread's column */
+    uint32_t cur;    /* LDS byte address of row `depth` */
+    __device__ __forceinline__ LdsStack()
     {
         extern __shared__ uint32_t s_dyn[];
-        uint32_t n = s_dyn[g < n_top ? g : 0u];
+        origin = (uint32_t)(uintptr_t)s_dyn + threadIdx.x * 4u; /* low word of a flat LDS address = LDS address */
+        cur = origin;
+    }
+    __device__ __forceinline__ void reset() { cur = origin; }
+    __device__ __forceinline__ void push(uint32_t word) { *(lds_u32 *)(uintptr_t)(cur + kRowBytes) = word; cur += kRowBytes; }
+    __device__ __forceinline__ void up() { cur -= kRowBytes; }
+    __device__ __forceinline__ uint32_t peek_up(uint32_t k) const { return *(lds_u32 *)(uintptr_t)(cur + kRowBytes - k * kRowBytes); }
+    __device__ __forceinline__ uint32_t depth() const { return (cur - origin) / kRowBytes; }
+};
+
+#ifndef VR_FETCH_MODE
+#define VR_FETCH_MODE 0
+#endif
+/* Node fetch of the persistent kernel: heap positions below n_top come from the LDS copy of the top tree
+ * levels, deeper ones from global memory. */
+#if VR_FETCH_MODE == 0
+/* One flat load whose 64-bit address is put together by hand: the low word is 4 * g plus the low word of
+ * either base, the high word is either the LDS aperture or the high word of the node array's address.
+ * The node array must not cross a 4 GiB boundary (the allocation in vr_capi.hip sees to that), so the
+ * low-word add cannot carry. */
+struct TopFetch {
+    uint32_t g_lo, g_hi, l_lo, l_hi, n_top;
+    __device__ __forceinline__ TopFetch(const uint32_t *nodes, const uint32_t *lds_top, uint32_t n_top_)
+    {
+        const uint64_t ga = (uint64_t)(uintptr_t)nodes, la = (uint64_t)(uintptr_t)(const void *)lds_top;
+        g_lo = (uint32_t)ga; g_hi = (uint32_t)(ga >> 32);
+        l_lo = (uint32_t)la; l_hi = (uint32_t)(la >> 32);
+        n_top = n_top_;
+        /* held in vector registers for the whole kernel: a select needs both of its inputs there, and the
+         * compiler would otherwise copy them out of scalar registers at every use */
+        asm volatile("" : "+v"(g_lo), "+v"(g_hi), "+v"(l_lo), "+v"(l_hi));
+    }
+    __device__ __forceinline__ uint32_t operator()(uint32_t g) const
+    {
+        const bool top = g < n_top;
+        const uint32_t lo = (top ? l_lo : g_lo) + (g << 2);
+        const uint32_t hi = top ? l_hi : g_hi;
+        return *(const uint32_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    }
+};
+#elif VR_FETCH_MODE == 1
+struct TopFetch {
+    const uint32_t *nodes;
+    const uint32_t *lds_top;
+    uint32_t n_top;
+    __device__ __forceinline__ TopFetch(const uint32_t *nodes_, const uint32_t *lds_top_, uint32_t n_top_)
+        : nodes(nodes_), lds_top(lds_top_), n_top(n_top_) {}
+    __device__ __forceinline__ uint32_t operator()(uint32_t g) const
+    {
+        uint32_t n = *(const volatile uint32_t *)(lds_top + (g < n_top ? g : 0u));
         if (g >= n_top) n = nodes[g];
         return n;
     }
 };
+#else
+struct TopFetch {
+    const uint32_t *nodes;
+    __device__ __forceinline__ TopFetch(const uint32_t *nodes_, const uint32_t *, uint32_t) : nodes(nodes_) {}
+    __device__ __forceinline__ uint32_t operator()(uint32_t g) const { return nodes[g]; }
+};
+#endif
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
 {
@@ -150,7 +194,7 @@ __global__ __launch_bounds__(256) void vr_k_render(VrViewK v, const uint32_t *__
         } else if (VARIANT == VR_KERNEL_RESTART_LDS) {
             h = vr_trace_restart(v, ray, iso, TopLdsFetch{ nodes, s_top });
         } else {
-            LdsStack<256u> st(s_dyn);
+            LdsStack<256u> st;
             h = vr_trace_resume(v, ray, iso, GlobalFetch{ nodes }, st, 64u);
         }
         const uint64_t pix = ((uint64_t)blockIdx.y * n_rows + yr) * v.width + xi;
@@ -187,12 +231,27 @@ __global__ __launch_bounds__(256) void vr_k_render(VrViewK v, const uint32_t *__
 
 /* ---------------------------------------------------------------- pipeline: pre-pass ---- */
 
-/* tile t covers pixels [8*(t % tiles_x), +8) x [8*(t / tiles_x), +8) of the rendered row range */
-__device__ __forceinline__ bool tile_ray(const VrViewK &v, uint32_t tile, uint32_t lane, uint32_t tiles_x,
-                                         uint32_t row_begin, uint32_t n_rows, VrRay &ray, uint32_t &pix)
+#ifndef VR_SUPER_TILE
+#define VR_SUPER_TILE 4
+#endif
+/* Tiles are numbered super-tile by super-tile (kSuper x kSuper tiles, row-major inside and across), so that
+ * rays next to each other in the compacted list -- which waves of one CU work on at the same time -- come from
+ * a compact square of the image and walk the same part of the tree.  The tile grid is padded to whole
+ * super-tiles; tiles outside the image hold no rays. */
+constexpr uint32_t kSuper = VR_SUPER_TILE;
+__host__ __device__ __forceinline__ uint32_t super_tiles_x(uint32_t width) { return (width + kTileW * kSuper - 1) / (kTileW * kSuper); }
+__host__ __device__ __forceinline__ uint32_t super_tiles_y(uint32_t n_rows) { return (n_rows + kTileH * kSuper - 1) / (kTileH * kSuper); }
+__host__ __device__ __forceinline__ uint32_t padded_tiles(uint32_t width, uint32_t n_rows)
 {
-    const uint32_t xi = (tile % tiles_x) * kTileW + (lane & 7u);
-    const uint32_t yr = (tile / tiles_x) * kTileH + (lane >> 3);
+    return super_tiles_x(width) * super_tiles_y(n_rows) * kSuper * kSuper;
+}
+
+__device__ __forceinline__ bool tile_ray(const VrViewK &v, uint32_t tile, uint32_t lane, uint32_t row_begin, uint32_t n_rows,
+                                         VrRay &ray, uint32_t &pix)
+{
+    const uint32_t st = tile / (kSuper * kSuper), in = tile % (kSuper * kSuper), sx = super_tiles_x(v.width);
+    const uint32_t xi = ((st % sx) * kSuper + in % kSuper) * kTileW + (lane & 7u);
+    const uint32_t yr = ((st / sx) * kSuper + in / kSuper) * kTileH + (lane >> 3);
     pix = yr * v.width + xi;
     if (xi >= v.width || yr >= n_rows) return false;
     ray = vr_make_ray(v, xi, yr + row_begin);
@@ -205,10 +264,9 @@ __global__ __launch_bounds__(256) void vr_k_count(VrViewK v, uint32_t row_begin,
 {
     const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (tile >= n_tiles) return;
-    const uint32_t tiles_x = (v.width + kTileW - 1) / kTileW;
     VrRay ray;
     uint32_t pix;
-    const bool active = tile_ray(v, tile, lane, tiles_x, row_begin, n_rows, ray, pix);
+    const bool active = tile_ray(v, tile, lane, row_begin, n_rows, ray, pix);
     const unsigned long long m = __ballot(active);
     if (lane == 0) tile_count[tile] = (uint32_t)__popcll(m);
 }
@@ -247,10 +305,9 @@ __global__ __launch_bounds__(256) void vr_k_compact(VrViewK v, uint32_t row_begi
 {
     const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (tile >= n_tiles) return;
-    const uint32_t tiles_x = (v.width + kTileW - 1) / kTileW;
     VrRay ray;
     uint32_t pix;
-    const bool active = tile_ray(v, tile, lane, tiles_x, row_begin, n_rows, ray, pix);
+    const bool active = tile_ray(v, tile, lane, row_begin, n_rows, ray, pix);
     const unsigned long long m = __ballot(active);
     if (active) {
         const uint32_t slot = tile_off[tile] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -280,7 +337,7 @@ __global__ void vr_k_tap_defaults(VrTapsK taps, uint64_t n)
 /* --------------------------------------------------------- pipeline: persistent trace ---- */
 
 #ifdef VR_DIAG /* diagnostic build only: where a wave's cycles go (never compiled into the product library) */
-__device__ unsigned long long g_diag[16];
+__device__ unsigned long long g_diag[20];
 __device__ __forceinline__ uint32_t wave_max(uint32_t x)
 {
 #pragma unroll
@@ -294,10 +351,22 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t x)
 #define DIAG_ADD(i, val)
 #endif
 
-constexpr uint32_t kTraceThreads = 1024; /* one block of 16 waves per CU */
+#ifndef VR_TRACE_THREADS
+#define VR_TRACE_THREADS 1024
+#endif
+constexpr uint32_t kTraceThreads = VR_TRACE_THREADS;
+#ifndef VR_TRACE_BLOCKS_PER_CU
+#define VR_TRACE_BLOCKS_PER_CU 1
+#endif
+/* resident blocks per CU.  One block of 16 waves (4 per SIMD) keeps the vector ALUs about 70 % busy; with
+ * more waves the per-CU vector L1 starts to thrash (hit rate 95 % -> 85 % at 8 per SIMD) and the sweep
+ * gets slower, not faster. */
+constexpr uint32_t kTraceBlocksPerCu = VR_TRACE_BLOCKS_PER_CU;
+constexpr uint32_t kTraceWavesPerSimd = kTraceThreads / 64u * kTraceBlocksPerCu / 4u;
 
 template <bool TAPS>
-__global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top,
+__global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top,
+                                                            uint32_t stack_rows,
                                                             const float4 *__restrict__ ray_dt,
                                                             const uint32_t *__restrict__ ray_pix,
                                                             const uint32_t *__restrict__ n_active_ptr,
@@ -306,12 +375,15 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
                                                             uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
                                                             VrTapsK taps)
 {
-    /* dynamic LDS: [n_top node words: heap positions 0 .. n_top-1][path stacks: (levels + 1) x kTraceThreads words] */
+    /* dynamic LDS: [path stacks: stack_rows x kTraceThreads words][n_top node words: heap positions 0 .. n_top-1] */
     extern __shared__ uint32_t s_dyn[];
-    for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_dyn[i] = nodes[i];
+    uint32_t *s_top = s_dyn + stack_rows * kTraceThreads;
+#if VR_FETCH_MODE != 2
+    for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_top[i] = nodes[i];
     __syncthreads();
-    LdsStack<kTraceThreads> stack(s_dyn + n_top);
-    const TopFetch fetch{ nodes, n_top };
+#endif
+    LdsStack<kTraceThreads> stack;
+    const TopFetch fetch(nodes, s_top, n_top);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_active = *n_active_ptr;
@@ -319,9 +391,15 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
     const uint32_t n_waves = gridDim.x * waves_per_block, gw = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     /* spread the waves over the iso queues; each wave then walks all queues cyclically, so waves that
      * run out of work on a cheap iso value move on to help with the expensive ones */
+#if defined(VR_K0_SPREAD)
+    /* experiment: the waves of one block start on different iso values */
+    const uint32_t k0 = (uint32_t)((((uint64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x) * iso_count) / n_waves);
+#else
     const uint32_t k0 = (uint32_t)(((uint64_t)gw * iso_count) / n_waves);
+#endif
 #ifdef VR_DIAG
-    unsigned long long d_acc[16] = { 0 };
+    unsigned long long d_acc[20] = { 0 };
+    unsigned long long d_refills = 0;
     DIAG_T(d_begin);
 #endif
 
@@ -356,7 +434,9 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
                     popping = false;
                 }
                 exhausted = base + n_idle >= n_active;
-                DIAG_ADD(12, 1);
+#ifdef VR_DIAG
+                d_refills++;
+#endif
             }
             if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
             DIAG_T(d_t1);
@@ -364,7 +444,8 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
             DIAG_ADD(5, 1);
             DIAG_ADD(10, __popcll(__ballot(alive)));
 #ifdef VR_DIAG
-            uint32_t d_trips = 0, d_pops = 0;
+            uint32_t d_trips = 0, d_pops = 0, d_lanes_d = 0, d_lanes_m = 0, d_lanes_p = 0;
+            unsigned long long d_ta = 0, d_tb = 0;
 #endif
 
             if (alive) {
@@ -379,6 +460,11 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
                     d_trips = stack.depth() - d_trips + (go != VR_GO_MORE ? 1u : 0u);
 #endif
                 }
+#ifdef VR_DIAG
+                d_lanes_d = popping ? 0u : 1u;
+                d_lanes_m = go == VR_GO_EXCLUDED ? 1u : 0u;
+                d_ta = __builtin_amdgcn_s_memtime();
+#endif
                 if (go == VR_GO_HIT) { /* shade and store (src/raytrace.zig:56-61) */
                     const uint8_t g = vr_shade(L.t);
                     frame[(uint64_t)pix * 3u + 0u] = g;
@@ -405,10 +491,14 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
                         }
                     }
                 }
+#ifdef VR_DIAG
+                d_tb = __builtin_amdgcn_s_memtime();
+#endif
                 if (alive && popping) {
                     /* ---- pop to the lowest ancestor that holds the new point (bounded) ---- */
 #ifdef VR_DIAG
                     d_pops = stack.depth();
+                    d_lanes_p = 1;
 #endif
                     popping = !vr_lane_pop(L, stack, kPopTrips);
 #ifdef VR_DIAG
@@ -429,6 +519,14 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
                 DIAG_ADD(1, d_t3 - d_t1); /* everything after the refill */
                 const uint32_t m1 = wave_max(d_trips), s1 = wave_sum(d_trips), m2 = wave_max(d_pops), s2 = wave_sum(d_pops);
                 DIAG_ADD(6, m1); DIAG_ADD(7, s1); DIAG_ADD(8, m2); DIAG_ADD(9, s2);
+                DIAG_ADD(2, wave_sum(d_lanes_d)); DIAG_ADD(3, wave_sum(d_lanes_m)); DIAG_ADD(4, wave_sum(d_lanes_p));
+                DIAG_ADD(14, wave_max(d_lanes_m));
+                {
+                    /* phase boundaries as seen by the first lane that ran the phases */
+                    const unsigned long long ta = __shfl(d_ta, __ffsll(__ballot(d_ta != 0)) - 1, 64);
+                    const unsigned long long tb = __shfl(d_tb, __ffsll(__ballot(d_tb != 0)) - 1, 64);
+                    if (ta && tb) { DIAG_ADD(15, ta - d_t1); d_acc[13] += tb - ta; d_acc[12] += d_t3 - tb; }
+                }
             }
 #endif
         }
@@ -453,9 +551,10 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
     {
         DIAG_T(d_end);
         d_acc[11] = d_end - d_begin;
-        d_acc[13] = 1;
+        d_acc[16] = 1;
+        d_acc[17] = d_refills;
         if (lane == 0)
-            for (int i = 0; i < 16; i++) atomicAdd(&g_diag[i], d_acc[i]);
+            for (int i = 0; i < 20; i++) atomicAdd(&g_diag[i], d_acc[i]);
     }
 #endif
 }
@@ -465,7 +564,7 @@ __global__ __launch_bounds__(kTraceThreads) void vr_k_trace(VrViewK v, const uin
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count)
 {
     const size_t n_pix = (size_t)width * n_rows;
-    const size_t n_tiles = (size_t)((width + kTileW - 1) / kTileW) * ((n_rows + kTileH - 1) / kTileH);
+    const size_t n_tiles = padded_tiles(width, n_rows);
     size_t bytes = 0;
     bytes += (n_pix * sizeof(float4) + 255) & ~(size_t)255; /* ray_dt     */
     bytes += (n_pix * sizeof(uint32_t) + 255) & ~(size_t)255; /* ray_pix    */
@@ -482,6 +581,11 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
 {
     const uint32_t n_rows = row_end - row_begin;
     const uint32_t stack_levels = max_depth > 0 ? max_depth : 1u;
+    {
+        /* the persistent kernel adds 32-bit offsets to the low word of the node array's address */
+        const uintptr_t p = (uintptr_t)d_nodes_prepared, last = p + (view.n_slots + 1u) * sizeof(uint32_t) - 1u;
+        if (variant == VR_KERNEL_PIPELINE && (p >> 32) != (last >> 32)) variant = VR_KERNEL_RESUME;
+    }
     const size_t stack_bytes = ((size_t)stack_levels + 1u) * 256u * sizeof(uint32_t); /* + the spare row above the root */
     hipError_t e;
 
@@ -511,8 +615,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
 
     /* ---- pipeline ---- */
     const size_t n_pix = (size_t)view.width * n_rows;
-    const uint32_t tiles_x = (view.width + kTileW - 1) / kTileW, tiles_y = (n_rows + kTileH - 1) / kTileH;
-    const uint32_t n_tiles = tiles_x * tiles_y;
+    const uint32_t n_tiles = padded_tiles(view.width, n_rows);
     char *w = (char *)workspace;
     float4 *ray_dt = (float4 *)w;
     w += (n_pix * sizeof(float4) + 255) & ~(size_t)255;
@@ -540,7 +643,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
 
     /* persistent grid: one 1024-thread block per CU.  Its LDS holds the path stacks and, in what is left of
      * the CU's 160 KiB, the top K levels of the tree (which take two thirds of all node reads). */
-    const size_t lds_limit = 160u * 1024u;
+    const size_t lds_limit = 160u * 1024u / kTraceBlocksPerCu;
     const size_t trace_stack_bytes = ((size_t)stack_levels + 1u) * kTraceThreads * sizeof(uint32_t);
     uint32_t top_levels = 14;
     if (const char *tune = getenv("VR_TUNE_TOP_LEVELS")) top_levels = (uint32_t)atoi(tune); /* experiment knob */
@@ -557,9 +660,10 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit)) != hipSuccess) return e;
         lds_set[any_tap ? 1 : 0] = true;
     }
-    const uint32_t blocks = (uint32_t)n_cus;
+    const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
     const uint64_t frame_pixels = n_pix;
-    void *args[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&ray_dt, (void *)&ray_pix,
+    const uint32_t stack_rows = stack_levels + 1u;
+    void *args[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                      (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                      (void *)&d_rgb, (void *)&d_stats, (void *)&taps };
 
@@ -569,18 +673,21 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
 #ifdef VR_DIAG
     {
-        unsigned long long h[16], z[16] = { 0 };
+        unsigned long long h[20], z[20] = { 0 };
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z);
-        const double w = (double)h[13], it = (double)h[5];
+        const double w = (double)h[16], it = (double)h[5];
         fprintf(stderr,
-                "[diag] waves %.0f  cycles/wave %.0f  outer its/wave %.0f  refill events/wave %.0f\n"
-                "[diag] per outer it: refill %.0f cyc, rest %.0f cyc; alive lanes %.1f\n"
-                "[diag] descend trips: wave %.2f lane-mean %.2f ; pops: wave %.2f lane-mean %.2f\n"
-                "[diag] per outer it: descend phase %.0f cyc, move..end-of-pop %.0f cyc (%.0f%% of its had a move)\n",
-                w, h[11] / w, it / w, h[12] / w, h[0] / it, h[1] / it, h[10] / it, h[6] / it, h[7] / (double)h[10],
-                h[8] / it, h[9] / (double)h[10], h[2] / it, (double)(h[4] - h[3]) / (double)h[14], 100.0 * h[14] / it);
+                "[diag] waves %.0f  cycles/wave %.0f  rounds/wave %.0f  refill events/wave %.0f\n"
+                "[diag] per round: refill %.0f cyc, rest %.0f cyc; alive lanes %.1f\n"
+                "[diag] lanes per round: descending %.1f, moving %.1f (rounds with a move %.0f%%), popping %.1f\n"
+                "[diag] descend trips per round: wave max %.2f, mean over descending lanes %.2f\n"
+                "[diag] pop trips per round: wave max %.2f, mean over popping lanes %.2f\n"
+                "[diag] cycles per round: descend %.0f (%.0f per trip), move + store %.0f, pop %.0f (%.0f per trip)\n",
+                w, h[11] / w, it / w, h[17] / w, h[0] / it, h[1] / it, h[10] / it, h[2] / it, h[3] / it,
+                100.0 * h[14] / it, h[4] / it, h[6] / it, h[7] / (double)h[2], h[8] / it, h[9] / (double)h[4],
+                h[15] / it, h[15] / (double)h[6], h[13] / it, h[12] / it, h[12] / (double)h[8]);
     }
 #endif
     return hipSuccess;

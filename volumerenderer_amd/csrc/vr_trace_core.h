@@ -46,6 +46,35 @@ VR_HD bool vr_box_contains_cell(uint32_t lo, uint32_t hi, uint32_t c)
     return ((a & b) & VR_F_GUARD) == VR_F_GUARD;
 }
 
+/* 2 * g + bit: on the GPU one add-with-carry fed by the compare's lane mask */
+VR_HD uint32_t vr_twice_plus(uint32_t g, bool bit)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long carry_in = __builtin_amdgcn_ballot_w64(bit);
+    unsigned long long carry_out;
+    uint32_t r;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(g), "s"(carry_in));
+    return r;
+#else
+    return 2u * g + (bit ? 1u : 0u);
+#endif
+}
+
+/* floor(x) as a saturating i32 (NaN -> 0): one conversion instruction on the GPU */
+VR_HD int32_t vr_floor_i32(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT32_MAX;
+    if (x < -2147483648.0f) return INT32_MIN;
+    return (int32_t)floorf(x);
+#endif
+}
+
 /* uniform per-launch constants */
 struct VrViewK {
     float ox, oy, oz;   /* src                                   */
@@ -223,8 +252,8 @@ VR_HD VrHit vr_trace_restart(const VrViewK &v, const VrRay &ray, uint32_t iso, N
  * bit for bit (vr_div).
  *
  * `Stack` is a cursor over the lane's path stack: push(word) stores at the current level and moves
- * one level down, pop() moves one level up and returns that level's word, peek_up(k) returns the
- * word k levels above the cursor without moving, depth() is the current level.
+ * one level down, up() moves one level up, peek_up(k) returns the word k levels above the cursor
+ * without moving, depth() is the current level.
  * ---------------------------------------------------------------------------------------- */
 #define VR_N_LEAF 0x80000000u
 #define VR_MAX_CHECKED (1u << 27) /* safety valve per ray; a 256^3 volume stays far below it */
@@ -242,17 +271,19 @@ VR_HD float vr_div(float n, float d, float r)
     return fmaf(e1, r, q1);
 }
 
-/* Plane.rayIntersect (src/geo.zig:406-426) with the division done by vr_div */
+/* Plane.rayIntersect (src/geo.zig:406-426) with the division done by vr_div.  For an axis the ray is
+ * parallel to (|d| < 1e-8: "no intersection", INFINITY in the reference's min) the lane holds r = NaN:
+ * the quotient is NaN, passes the `t > 0` select untouched and drops out of the minimum over the three
+ * axes (fminf returns the other operand), which is what INFINITY does there. */
 VR_HD float vr_plane_t_r(float off, float o, float d, float r)
 {
     const float t = vr_div(off - o, d, r);
-    const float u = t > 0.0f ? t : -1.0f;
-    return fabsf(d) < 1e-8f ? INFINITY : u;
+    return t <= 0.0f ? -1.0f : t;
 }
 
 struct VrLane {
     float dx, dy, dz, t;
-    float rx, ry, rz; /* 1 / d per axis, correctly rounded */
+    float rx, ry, rz; /* 1 / d per axis, correctly rounded; NaN where |d| < 1e-8 (see vr_plane_t_r) */
     uint32_t cell;    /* packed floor(point), valid while the point is inside the root box */
     uint32_t lo, hi;  /* packed box of the current node */
     uint32_t g;       /* 1-based heap position of the current node */
@@ -264,7 +295,9 @@ template <class Stack>
 VR_HD void vr_lane_begin(VrLane &L, Stack &stack, const VrViewK &v, float dx, float dy, float dz, float t)
 {
     L.dx = dx; L.dy = dy; L.dz = dz; L.t = t;
-    L.rx = 1.0f / dx; L.ry = 1.0f / dy; L.rz = 1.0f / dz;
+    L.rx = fabsf(dx) < 1e-8f ? NAN : 1.0f / dx;
+    L.ry = fabsf(dy) < 1e-8f ? NAN : 1.0f / dy;
+    L.rz = fabsf(dz) < 1e-8f ? NAN : 1.0f / dz;
     /* inside the root box every coordinate is >= 0, so trunc == floor */
     L.cell = vr_pack10((uint32_t)(v.ox + dx * t), (uint32_t)(v.oy + dy * t), (uint32_t)(v.oz + dz * t));
     L.lo = 0; L.hi = v.root_hi;
@@ -290,18 +323,21 @@ VR_HD uint32_t vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stac
 {
     const uint32_t d0 = stack.depth();
     uint32_t out = VR_GO_MORE;
+#if defined(VR_DESCEND_UNROLLED)
+#pragma unroll
+#endif
     for (uint32_t trip = 0; trip < max_trips; trip++) {
         const uint32_t n = fetch(L.g);
         const bool holds = vr_node_holds(n, iso);
         if (!holds || (n & VR_N_LEAF)) { out = holds ? VR_GO_HIT : VR_GO_EXCLUDED; break; }
         const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
-        const bool left = ((L.cell >> sh) & 0xffu) < part;
-        uint32_t side = left ? L.hi : L.lo;
-        stack.push(side);
+        const bool right = ((L.cell >> sh) & 0xffu) >= part;
+        uint32_t side = right ? L.lo : L.hi;
+        stack.push(side); /* the bound word the zoom replaces */
         side = (side & ~(0xffu << sh)) | (part << sh); /* partition is strictly inside the box: min/max of geo.zig:256-275 pick it */
-        L.hi = left ? side : L.hi;
-        L.lo = left ? L.lo : side;
-        L.g = 2u * L.g + (left ? 0u : 1u);
+        L.lo = right ? side : L.lo;
+        L.hi = right ? L.hi : side;
+        L.g = vr_twice_plus(L.g, right);
     }
     /* one check per node tested (src/raytrace.zig:162): every level passed, plus the node that ended the descent */
     L.checked += stack.depth() - d0 + (out != VR_GO_MORE ? 1u : 0u);
@@ -313,18 +349,19 @@ VR_HD uint32_t vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stac
 VR_HD bool vr_lane_move(VrLane &L, const VrViewK &v, uint32_t &escapes)
 {
     const uint32_t ex = (L.hi & L.posmask) | (L.lo & ~L.posmask); /* exit plane per axis: max if d >= 0 else min */
-    float t = INFINITY;
-    t = fminf(t, vr_plane_t_r((float)(ex & 0xffu), v.ox, L.dx, L.rx));
-    t = fminf(t, vr_plane_t_r((float)((ex >> 10) & 0xffu), v.oy, L.dy, L.ry));
-    t = fminf(t, vr_plane_t_r((float)((ex >> 20) & 0xffu), v.oz, L.dz, L.rz));
+    float t = fminf(fminf(vr_plane_t_r((float)(ex & 0xffu), v.ox, L.dx, L.rx),
+                          vr_plane_t_r((float)((ex >> 10) & 0xffu), v.oy, L.dy, L.ry)),
+                    vr_plane_t_r((float)((ex >> 20) & 0xffu), v.oz, L.dz, L.rz));
     t += 0.0001f;
     float i = 0.0f;
     bool in_root;
     for (;;) {
         const float px = v.ox + L.dx * t, py = v.oy + L.dy * t, pz = v.oz + L.dz * t;
-        in_root = vr_root_contains(v, px, py, pz);
+        /* Range.containsFloat per axis (src/geo.zig:173-176): 0 <= p < dim  <=>  floor(p), as unsigned, < dim */
+        const uint32_t cx = (uint32_t)vr_floor_i32(px), cy = (uint32_t)vr_floor_i32(py), cz = (uint32_t)vr_floor_i32(pz);
+        in_root = (cx < v.rdx) & (cy < v.rdy) & (cz < v.rdz);
         if (!in_root) break; /* outside the root is outside every node box */
-        L.cell = vr_pack10((uint32_t)px, (uint32_t)py, (uint32_t)pz);
+        L.cell = vr_pack10(cx, cy, cz);
         if (!vr_box_contains_cell(L.lo, L.hi, L.cell)) break;
         t += 0.001f * i;
         i += 1.0f;
@@ -337,8 +374,9 @@ VR_HD bool vr_lane_move(VrLane &L, const VrViewK &v, uint32_t &escapes)
 /* After a MOVE: pops ancestors until one holds the new point, then steps straight into that
  * ancestor's OTHER child.  (The ancestor A holds the point, its child C on the old path does not, and
  * A's two children tile A, so the point is in C's sibling; A itself passed its iso test on the way
- * down, so the reference's restarted walk goes root .. A .. sibling.  A is not read again: the split
- * field is the one where A's and C's cut bound differ, and the partition is C's value there.)
+ * down, so the reference's restarted walk goes root .. A .. sibling.  A is not read again: a stack
+ * word is the bound word the zoom into C replaced, the split field is the one where it differs from
+ * C's bound, and the partition is C's value there.)
  * Credits the depth(A)+1 node checks the reference spends on root .. A.  The stack word of the next
  * level up is requested before the current one is examined, so its latency hides behind the test.
  * At most `max_trips` levels per call; returns true when the sibling was entered, false when the
@@ -349,31 +387,38 @@ VR_HD bool vr_lane_pop(VrLane &L, Stack &stack, uint32_t max_trips)
 {
     const uint32_t cg = L.cell | VR_F_GUARD, cp = L.cell + VR_F_ONES;
     uint32_t next = stack.peek_up(1);
+    uint32_t word = 0;
+    bool left = false, found = false;
+#if defined(VR_POP_ROLLED)
+#pragma unroll 1
+#endif
     for (uint32_t trip = 0; trip < max_trips; trip++) {
-        const uint32_t word = next;        /* A's bound word that the zoom into C replaced */
-        stack.up();                        /* cursor at the level of the parent A */
-        next = stack.peek_up(1);           /* at the root this reads the spare row: never used */
-        const bool left = (L.g & 1u) == 0u; /* even position = left child: the zoom had cut hi */
-        const uint32_t c_lo = L.lo, c_hi = L.hi;
-        L.hi = left ? word : c_hi;
-        L.lo = left ? c_lo : word;
-        const uint32_t a = cg - L.lo, b = (L.hi | VR_F_GUARD) - cp; /* vr_box_contains_cell, shared parts hoisted */
-        if (((a & b) & VR_F_GUARD) == VR_F_GUARD) {
-            const uint32_t cut = left ? c_hi : c_lo;   /* C's cut side */
-            const uint32_t keep = left ? c_lo : c_hi;  /* the side C shares with A */
-            const uint32_t diff = word ^ cut;
-            const uint32_t fm = (diff & 0x3ffu) ? 0x3ffu : ((diff & 0xffc00u) ? 0xffc00u : 0x3ff00000u);
-            const uint32_t other = (keep & ~fm) | (cut & fm); /* sibling's new bound on the side it cuts */
-            stack.push(keep);
-            L.lo = left ? other : L.lo;
-            L.hi = left ? L.hi : other;
-            L.g ^= 1u;
-            L.checked += stack.depth();
-            return true;
-        }
+        word = next;                 /* A's bound word that the zoom into C replaced */
+        stack.up();                  /* cursor at the level of the parent A */
+        next = stack.peek_up(1);     /* at the root this reads the spare row: never used */
+        left = (L.g & 1u) == 0u;     /* even position = left child: the zoom had cut hi */
+        const uint32_t a_lo = left ? L.lo : word, a_hi = left ? word : L.hi;
+        const uint32_t a = cg - a_lo, b = (a_hi | VR_F_GUARD) - cp; /* vr_box_contains_cell, shared parts hoisted */
+        found = ((a & b) & VR_F_GUARD) == VR_F_GUARD;
+        if (found) break;            /* L.lo / L.hi are still C's */
+        L.lo = a_lo; L.hi = a_hi;
         L.g >>= 1;
     }
-    return false;
+    if (!found) return false;
+    /* zoom from A into the sibling of C: the sibling keeps A's bound on C's cut side (`word`) and cuts the
+     * side C shares with A at the partition, which is C's value in the one field where `word` and C's cut
+     * bound differ.  Adding 0xff to every field of the difference carries into the guard bit exactly where
+     * the field is not 0, which gives the field's mask. */
+    const uint32_t cut = left ? L.hi : L.lo, keep = left ? L.lo : L.hi;
+    const uint32_t carry = ((word ^ cut) + 0xffu * VR_F_ONES) & VR_F_GUARD;
+    const uint32_t fm = carry - (carry >> 8);
+    const uint32_t other = (keep & ~fm) | (cut & fm);
+    stack.push(keep);
+    L.lo = left ? other : word;
+    L.hi = left ? word : other;
+    L.g ^= 1u;
+    L.checked += stack.depth();
+    return true;
 }
 
 VR_HD uint32_t vr_unpack_cell(uint32_t c10) { return (c10 & 0xffu) | (((c10 >> 10) & 0xffu) << 8) | (((c10 >> 20) & 0xffu) << 16); }
