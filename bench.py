@@ -192,7 +192,7 @@ def main():
                        "kernel": capi.lib().vr_kernel_name(args.kernel).decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "vr_k_render", "kernel_ms": kernel_ms, "launches_timed": int(launches.value),
+                         "kernel": "vr_k_trace" if args.kernel in (0, 4) else "vr_k_render", "kernel_ms": kernel_ms, "launches_timed": int(launches.value),
                          "algorithmic_bytes_per_launch": alg_bytes, "nodes_checked_per_launch": nodes_checked},
             "errors": errors,
         }

@@ -16,10 +16,10 @@
  *    2. frames are zero-filled (OOB and miss pixels are black, src/raytrace.zig:54,67).
  *    3. persistent trace kernel, one 1024-thread block per CU: the top 14 levels of the tree (which
  *       take two thirds of all node reads) sit in LDS, because what bounds this path on the chip is
- *       the vector L1's rate for 64-address gathers, not HBM and not the VALU.  Waves pull rays of
- *       one iso value at a time from that iso's queue and refill idle lanes as their rays finish.
- *       Traversal resumes from the lowest valid ancestor after each MOVE (path stack in LDS) instead
- *       of restarting at the root.  Only hit pixels are stored.
+ *       the latency of the vector L1 path under load (more resident waves make it thrash), not HBM
+ *       and not the VALU.  Waves pull rays of one iso value at a time from that iso's queue and refill
+ *       idle lanes as their rays finish.  Traversal resumes from the lowest valid ancestor after each
+ *       MOVE (path stack in LDS) instead of restarting at the root.  Only hit pixels are stored.
  */
 #include <cstdio>
 #include <cstdlib>
@@ -89,13 +89,9 @@ struct LdsStack {
     __device__ __forceinline__ uint32_t depth() const { return (cur - origin) / kRowBytes; }
 };
 
-#ifndef VR_FETCH_MODE
-#define VR_FETCH_MODE 0
-#endif
 /* Node fetch of the persistent kernel: heap positions below n_top come from the LDS copy of the top tree
- * levels, deeper ones from global memory. */
-#if VR_FETCH_MODE == 0
-/* One flat load whose 64-bit address is put together by hand: the low word is 4 * g plus the low word of
+ * levels, deeper ones from global memory.
+ * One flat load whose 64-bit address is put together by hand: the low word is 4 * g plus the low word of
  * either base, the high word is either the LDS aperture or the high word of the node array's address.
  * The node array must not cross a 4 GiB boundary (the allocation in vr_capi.hip sees to that), so the
  * low-word add cannot carry. */
@@ -119,27 +115,6 @@ struct TopFetch {
         return *(const uint32_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
     }
 };
-#elif VR_FETCH_MODE == 1
-struct TopFetch {
-    const uint32_t *nodes;
-    const uint32_t *lds_top;
-    uint32_t n_top;
-    __device__ __forceinline__ TopFetch(const uint32_t *nodes_, const uint32_t *lds_top_, uint32_t n_top_)
-        : nodes(nodes_), lds_top(lds_top_), n_top(n_top_) {}
-    __device__ __forceinline__ uint32_t operator()(uint32_t g) const
-    {
-        uint32_t n = *(const volatile uint32_t *)(lds_top + (g < n_top ? g : 0u));
-        if (g >= n_top) n = nodes[g];
-        return n;
-    }
-};
-#else
-struct TopFetch {
-    const uint32_t *nodes;
-    __device__ __forceinline__ TopFetch(const uint32_t *nodes_, const uint32_t *, uint32_t) : nodes(nodes_) {}
-    __device__ __forceinline__ uint32_t operator()(uint32_t g) const { return nodes[g]; }
-};
-#endif
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
 {
@@ -378,10 +353,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
     /* dynamic LDS: [path stacks: stack_rows x kTraceThreads words][n_top node words: heap positions 0 .. n_top-1] */
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_top = s_dyn + stack_rows * kTraceThreads;
-#if VR_FETCH_MODE != 2
     for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_top[i] = nodes[i];
     __syncthreads();
-#endif
     LdsStack<kTraceThreads> stack;
     const TopFetch fetch(nodes, s_top, n_top);
 
@@ -391,12 +364,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
     const uint32_t n_waves = gridDim.x * waves_per_block, gw = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     /* spread the waves over the iso queues; each wave then walks all queues cyclically, so waves that
      * run out of work on a cheap iso value move on to help with the expensive ones */
-#if defined(VR_K0_SPREAD)
-    /* experiment: the waves of one block start on different iso values */
-    const uint32_t k0 = (uint32_t)((((uint64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x) * iso_count) / n_waves);
-#else
     const uint32_t k0 = (uint32_t)(((uint64_t)gw * iso_count) / n_waves);
-#endif
 #ifdef VR_DIAG
     unsigned long long d_acc[20] = { 0 };
     unsigned long long d_refills = 0;
@@ -641,8 +609,8 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     if (any_tap) hipLaunchKernelGGL(vr_k_tap_defaults, dim3(2048), dim3(256), 0, stream, taps, (uint64_t)n_pix * iso_count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
 
-    /* persistent grid: one 1024-thread block per CU.  Its LDS holds the path stacks and, in what is left of
-     * the CU's 160 KiB, the top K levels of the tree (which take two thirds of all node reads). */
+    /* persistent grid: kTraceBlocksPerCu blocks per CU.  A block's LDS holds the path stacks and, in what is
+     * left of its share of the CU's 160 KiB, the top K levels of the tree (two thirds of all node reads). */
     const size_t lds_limit = 160u * 1024u / kTraceBlocksPerCu;
     const size_t trace_stack_bytes = ((size_t)stack_levels + 1u) * kTraceThreads * sizeof(uint32_t);
     uint32_t top_levels = 14;

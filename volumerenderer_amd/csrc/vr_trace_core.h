@@ -323,9 +323,6 @@ VR_HD uint32_t vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stac
 {
     const uint32_t d0 = stack.depth();
     uint32_t out = VR_GO_MORE;
-#if defined(VR_DESCEND_UNROLLED)
-#pragma unroll
-#endif
     for (uint32_t trip = 0; trip < max_trips; trip++) {
         const uint32_t n = fetch(L.g);
         const bool holds = vr_node_holds(n, iso);
@@ -389,9 +386,6 @@ VR_HD bool vr_lane_pop(VrLane &L, Stack &stack, uint32_t max_trips)
     uint32_t next = stack.peek_up(1);
     uint32_t word = 0;
     bool left = false, found = false;
-#if defined(VR_POP_ROLLED)
-#pragma unroll 1
-#endif
     for (uint32_t trip = 0; trip < max_trips; trip++) {
         word = next;                 /* A's bound word that the zoom into C replaced */
         stack.up();                  /* cursor at the level of the parent A */
