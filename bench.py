@@ -7,7 +7,7 @@ reference camera (src/main.zig:31-43), i.e. 256 x 1 048 576 primary rays per ste
 rays count, including the ones that miss the volume -- the reference's ms/frame includes them too.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--gather]
-                    [--kernel V] [--width PX] [--no-cpu-baseline]
+                    [--kernel V] [--width PX] [--volume skull|c60|standin256] [--no-cpu-baseline]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`
 (one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE from the environment).  The path shards with no
@@ -25,7 +25,11 @@ ALGORITHMIC bytes 4 * nodes_checked + 3 * pixels (one 4-byte SlimNode per refere
 src/raytrace.zig:162,177, plus one RGB24 store per pixel, :54-67), its duration measured with HIP
 events on the launch stream.  `cpu_baseline` times the CPU oracle (a port of the reference's
 single-threaded path; the Zig reference cannot be built offline) on one host core on a bounded
-sample of the same workload.
+sample of the same workload; `cpu_all_cores` is the same oracle with the image rows spread over the
+host cores this job may use -- a whole-socket figure the reference itself does not have.
+`roofline.measured_copy_GBps` is a device-to-device copy timed in the same process (the HBM ceiling
+actually reachable, next to the nominal peak); `roofline.counters` repeats the VALU figures of the
+committed rocprofv3 counter pass.
 """
 import argparse
 import ctypes as C
@@ -64,9 +68,60 @@ def cpu_baseline(kdt, pos, forw, up, width, budget_s=20.0):
     except OSError:
         pass
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": "Skull %dx%d, isos %s (%d frames, %.1f s, tree build excluded), CPU: %s" % (
+            "sample": "%dx%d, isos %s (%d frames, %.1f s, tree build excluded), CPU: %s" % (
                 width, width, ",".join(map(str, done)), len(done), dt, model),
             "nodes_checked_per_frame": checks / max(1, len(done))}
+
+
+def cpu_all_cores(kdt, pos, forw, up, width, threads, budget_s=8.0):
+    """The oracle with the rows of each frame spread over `threads` host threads (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from oracle import oracle as O
+    bands = [(width * i // (4 * threads), width * (i + 1) // (4 * threads)) for i in range(4 * threads)]
+    done, rays = [], 0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as pool:
+        for iso in range(1, 256, 2):
+            img = np.zeros((width, width, 3), np.uint8)
+            list(pool.map(lambda b: O.render(kdt.nodes, kdt.root_dim, pos, forw, up, width, width, 2.0, iso, rows=b,
+                                             taps=False, out=img), bands))
+            done.append(iso)
+            rays += width * width
+            if time.perf_counter() - t0 > budget_s:
+                break
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port, rows over threads (not the reference)",
+            "sample": "%d frames (isos %d..%d step 2) in %.1f s" % (len(done), done[0], done[-1], dt)}
+
+
+def copy_ceiling_gbps(torch):
+    """Device-to-device copy of 1 GiB, read + write bytes over the best of 5 timings."""
+    a = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    best = 1e9
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del a, b
+    return 2.0 * (1 << 30) / (best * 1e-3) / 1e9
+
+
+def profile_counters():
+    """VALU figures of the committed counter pass (profiles/r01_pmc_summary.json), for the default workload."""
+    try:
+        s = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        k = [v for n, v in s.items() if "vr_k_trace" in n][0]
+        simd_quanta = k["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0  # cycles per XCD / 4-cycle issue slots x 1024 SIMDs
+        return {"valu_busy_frac": k["SQ_ACTIVE_INST_VALU"] / simd_quanta,
+                "valu_lane_util_frac": k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"]),
+                "waves_per_simd": k["SQ_WAVES"] / 1024.0, "source": "profiles/r01_pmc_summary.json"}
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
 
 
 def main():
@@ -78,6 +133,7 @@ def main():
     ap.add_argument("--gather", action="store_true")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--volume", choices=["skull", "c60", "standin256"], default="skull")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,13 +158,21 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W = H = args.width
-    data = vr.Data.loadUCD(os.path.join(ROOT, "tests", "data", "Skull.vol.gz"))
-    kdt = vr.SlimKDT.newHeursiticPartition(data, "AlwaysCenter")
+    if args.volume == "skull":
+        data = vr.Data.loadUCD(os.path.join(ROOT, "tests", "data", "Skull.vol.gz"))
+        what = "Skull.vol shipped by the reference (68x256x256 u8), reference camera; no synthetic stand-in"
+    elif args.volume == "c60":
+        data = vr.Data.loadUCD(os.path.join(ROOT, "tests", "data", "C60.vol"))
+        what = "C60.vol shipped by the reference (64^3 u8), reference camera"
+    else:
+        data = vr.Data(vr.datasets.bonsai_standin())
+        what = "synthetic 256^3 u8 stand-in for the 256^3 CT volume the reference does not ship (seeded, volumerenderer_amd/datasets.py)"
     pos, forw, up = vr.main_camera(data.resulution)
 
     L = capi.lib()
     r = vr.Renderer(local_rank)
-    r.upload_kdt(kdt)
+    r.upload_volume(data)
+    build = r.build_kdt("AlwaysCenter")  # centre-split tree built on the GPU from the uploaded volume
     r.set_kernel(args.kernel)
     if args.scaling == "strong":
         iso_begin, iso_count = sharding.iso_shard(rank, world, 0, 256)
@@ -172,7 +236,8 @@ def main():
             except (OSError, ValueError):
                 traffic = None
         out = {
-            "metric": "Mrays/s on the Skull.vol iso sweep (iso 0..255) at %dx%d" % (W, H),
+            "metric": "Mrays/s on the %s iso sweep (iso 0..255) at %dx%d" % (
+                {"skull": "Skull.vol", "c60": "C60.vol", "standin256": "256^3 stand-in"}[args.volume], W, H),
             "value": rays_per_step * args.steps / dt / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -183,9 +248,12 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "Skull.vol shipped by the reference (68x256x256 u8), reference camera; no synthetic stand-in",
-            "config": {"workload": "skull_%dx%d_iso0-255_sweep" % (W, H), "volume": "Skull 68x256x256",
-                       "tree": "SlimKDT AlwaysCenter, 2^24 slots", "rays_per_step": int(rays_per_step),
+            "data": what,
+            "config": {"workload": "%s_%dx%d_iso0-255_sweep" % (args.volume, W, H),
+                       "volume": "%s %dx%dx%d" % ((args.volume,) + tuple(data.resulution)),
+                       "tree": "SlimKDT AlwaysCenter built on the GPU, %d nodes, depth %d" % (
+                           build.number_of_nodes, build.layer_count),
+                       "rays_per_step": int(rays_per_step),
                        "sharding": "none" if world == 1 else ("iso-blocks" if args.scaling == "strong" else
                                                               "one sweep per rank"),
                        "gather": bool(args.gather and world > 1),
@@ -193,12 +261,19 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "vr_k_trace" if args.kernel in (0, 4) else "vr_k_render", "kernel_ms": kernel_ms, "launches_timed": int(launches.value),
-                         "algorithmic_bytes_per_launch": alg_bytes, "nodes_checked_per_launch": nodes_checked},
+                         "algorithmic_bytes_per_launch": alg_bytes, "nodes_checked_per_launch": nodes_checked,
+                         "measured_copy_GBps": copy_ceiling_gbps(torch),
+                         "counters": profile_counters() if (args.volume == "skull" and W == 1024) else None},
             "errors": errors,
         }
+        if args.volume != "skull" or W != 1024:
+            out["roofline"]["traffic"] = None  # the committed counter pass is for the default workload only
         if not args.no_cpu_baseline and world == 1:
+            kdt = vr.SlimKDT.newHeursiticPartition(data, "AlwaysCenter")  # host copy for the CPU legs
             out["cpu_baseline"] = cpu_baseline(kdt, pos, forw, up, W)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+            threads = max(1, min(16, len(os.sched_getaffinity(0))))
+            out["cpu_all_cores"] = cpu_all_cores(kdt, pos, forw, up, W, threads)
         print(json.dumps(out), flush=True)
     r.close()
     if world > 1:

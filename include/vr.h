@@ -111,6 +111,16 @@ const char *vr_strerror(int code);
  * bytes, x slowest / z fastest (src/Data.zig:90-92); release with vr_free. */
 int vr_load_ucd(const char *path, uint8_t **vox_out, uint32_t res_out[3]);
 
+/* The inverse of vr_load_ucd: writes vox in the .vol layout Data.loadUCD reads (src/Data.zig:9-44). */
+int vr_save_ucd(const char *path, const uint8_t *vox, const uint32_t res[3]);
+
+/* Tree cache file: what the reference's saveToFile stub (src/___SlimKDT_.zig:266-269) was meant to
+ * be.  Stores the SlimNode array (src/SlimKDT.zig:15-19: root_dim + nodes) without its trailing
+ * unoccupied slots, with a checksum; vr_load_kdt returns the full-length array (release with
+ * vr_free) ready for vr_upload_kdt.  VR_EFORMAT on a bad magic, size or checksum. */
+int vr_save_kdt(const char *path, const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3]);
+int vr_load_kdt(const char *path, uint32_t **nodes_out, uint64_t *n_slots_out, uint8_t root_dim_out[3]);
+
 /* SlimKDT.newHeursiticPartition (src/SlimKDT.zig:222-322) on the host.  Produces the heap-indexed
  * (children of i at 2i+1 / 2i+2, :24-30) array of 4-byte SlimNode words (:9-13: byte0 min, byte1
  * max, byte2 partition, byte3 axis).  Slots no node occupies are 0.  max_slots = 0 means 2^32.

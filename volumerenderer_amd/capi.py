@@ -35,7 +35,7 @@ HEURISTICS = {
 
 # every symbol include/vr.h declares; tests check that the library exports each of them
 EXPORTS = [
-    "vr_strerror", "vr_load_ucd", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
+    "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
     "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_render",
     "vr_render_sweep", "vr_render_device", "vr_sync", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
@@ -87,6 +87,9 @@ def lib():
     L.vr_strerror.argtypes = [C.c_int]
     L.vr_strerror.restype = C.c_char_p
     L.vr_load_ucd.argtypes = [C.c_char_p, C.POINTER(u8p), u32p]
+    L.vr_save_ucd.argtypes = [C.c_char_p, vp, u32p]
+    L.vr_save_kdt.argtypes = [C.c_char_p, vp, C.c_uint64, u8p]
+    L.vr_load_kdt.argtypes = [C.c_char_p, C.POINTER(u32p), C.POINTER(C.c_uint64), u8p]
     L.vr_host_build_kdt.argtypes = [vp, u32p, C.c_int, C.c_uint64, C.POINTER(u32p), C.POINTER(C.c_uint64), u8p,
                                     C.POINTER(BuildStats)]
     L.vr_host_prepare_kdt.argtypes = [vp, C.c_uint64, u8p, vp, C.c_uint64, u32p, C.POINTER(C.c_uint64)]

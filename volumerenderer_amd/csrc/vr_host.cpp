@@ -230,6 +230,82 @@ int vr_load_ucd(const char *path, uint8_t **vox_out, uint32_t res_out[3])
     return VR_OK;
 }
 
+/* The .vol layout of Data.loadUCD (src/Data.zig:9-44) written back: 3 x u32 BE dims, one unused u32,
+ * three BE f32 "true size" values (1.0 here; the loader ignores them), then the voxel bytes verbatim. */
+int vr_save_ucd(const char *path, const uint8_t *vox, const uint32_t res[3])
+{
+    if (!path || !vox || !res || !res[0] || !res[1] || !res[2]) return VR_EARG;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return VR_EIO;
+    uint8_t hdr[28] = { 0 };
+    for (int a = 0; a < 3; a++) {
+        hdr[4 * a + 0] = (uint8_t)(res[a] >> 24); hdr[4 * a + 1] = (uint8_t)(res[a] >> 16);
+        hdr[4 * a + 2] = (uint8_t)(res[a] >> 8);  hdr[4 * a + 3] = (uint8_t)res[a];
+        hdr[16 + 4 * a] = 0x3f; hdr[17 + 4 * a] = 0x80; /* 1.0f, big endian */
+    }
+    const uint64_t n = (uint64_t)res[0] * res[1] * res[2];
+    const bool ok = std::fwrite(hdr, 1, sizeof hdr, f) == sizeof hdr && std::fwrite(vox, 1, n, f) == n;
+    return (std::fclose(f) == 0 && ok) ? VR_OK : VR_EIO;
+}
+
+/* Tree cache file (the reference only has a stub for it, src/___SlimKDT_.zig:266-269): the heap-indexed
+ * SlimNode array with its trailing unoccupied slots cut off.
+ *   bytes 0-7   "VRKDT\0\1\0"            magic + format version 1
+ *   bytes 8-10  root_dim, byte 11 0
+ *   bytes 12-15 0
+ *   bytes 16-23 n_slots   (u64 LE)  length of the array in memory
+ *   bytes 24-31 n_stored  (u64 LE)  words that follow (index of the last non-zero word + 1)
+ *   bytes 32-39 FNV-1a 64 of the stored words' bytes
+ *   then n_stored u32 LE words */
+namespace {
+const uint8_t kKdtMagic[8] = { 'V', 'R', 'K', 'D', 'T', 0, 1, 0 };
+uint64_t fnv1a64(const uint8_t *p, uint64_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+void put64(uint8_t *p, uint64_t v) { for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i)); }
+uint64_t get64(const uint8_t *p) { uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | p[i]; return v; }
+} // namespace
+
+int vr_save_kdt(const char *path, const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3])
+{
+    if (!path || !nodes || !n_slots || !root_dim) return VR_EARG;
+    uint64_t n_stored = n_slots;
+    while (n_stored > 0 && nodes[n_stored - 1] == 0u) n_stored--;
+    uint8_t hdr[40] = { 0 };
+    std::memcpy(hdr, kKdtMagic, 8);
+    hdr[8] = root_dim[0]; hdr[9] = root_dim[1]; hdr[10] = root_dim[2];
+    put64(hdr + 16, n_slots);
+    put64(hdr + 24, n_stored);
+    put64(hdr + 32, fnv1a64((const uint8_t *)nodes, n_stored * 4));
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return VR_EIO;
+    const bool ok = std::fwrite(hdr, 1, sizeof hdr, f) == sizeof hdr && std::fwrite(nodes, 4, n_stored, f) == n_stored;
+    return (std::fclose(f) == 0 && ok) ? VR_OK : VR_EIO;
+}
+
+int vr_load_kdt(const char *path, uint32_t **nodes_out, uint64_t *n_slots_out, uint8_t root_dim_out[3])
+{
+    if (!path || !nodes_out || !n_slots_out || !root_dim_out) return VR_EARG;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return VR_EIO;
+    uint8_t hdr[40];
+    if (std::fread(hdr, 1, sizeof hdr, f) != sizeof hdr || std::memcmp(hdr, kKdtMagic, 8) != 0) { std::fclose(f); return VR_EFORMAT; }
+    const uint64_t n_slots = get64(hdr + 16), n_stored = get64(hdr + 24);
+    if (n_slots == 0 || n_slots > ((uint64_t)1 << 32) || n_stored > n_slots) { std::fclose(f); return VR_EFORMAT; }
+    uint32_t *nodes = (uint32_t *)std::calloc(n_slots, 4);
+    if (!nodes) { std::fclose(f); return VR_ENOMEM; }
+    const bool ok = std::fread(nodes, 4, n_stored, f) == n_stored && fnv1a64((const uint8_t *)nodes, n_stored * 4) == get64(hdr + 32);
+    std::fclose(f);
+    if (!ok) { std::free(nodes); return VR_EFORMAT; }
+    *nodes_out = nodes;
+    *n_slots_out = n_slots;
+    root_dim_out[0] = hdr[8]; root_dim_out[1] = hdr[9]; root_dim_out[2] = hdr[10];
+    return VR_OK;
+}
+
 int vr_host_build_kdt(const uint8_t *vox, const uint32_t res[3], int heuristic, uint64_t max_slots,
                       uint32_t **nodes_out, uint64_t *n_slots_out, uint8_t root_dim_out[3], vr_build_stats *stats_out)
 {

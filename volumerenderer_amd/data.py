@@ -42,6 +42,12 @@ class Data:
         L.vr_free(p)
         return Data(arr)
 
+    def saveUCD(self, file_name):
+        """Writes the volume in the layout loadUCD reads (the reference has a loader only)."""
+        res = (C.c_uint32 * 3)(*self.resulution)
+        vox = np.ascontiguousarray(self.data, dtype=np.uint8)
+        capi.check(capi.lib().vr_save_ucd(os.fsencode(os.fspath(file_name)), vox.ctypes.data, res), "vr_save_ucd")
+
     def get(self, x, y, z):
         """src/Data.zig:90-92"""
         return int(self.data[x, y, z])

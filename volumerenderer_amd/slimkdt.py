@@ -1,5 +1,6 @@
 """SlimKDT: the min/max KD-tree over cells the ray caster walks (src/SlimKDT.zig)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -15,6 +16,23 @@ class SlimKDT:
         self.root_dim = np.ascontiguousarray(root_dim, dtype=np.uint8)
         self.build = build
         self.data = data
+
+    def saveToFile(self, file_name):
+        """Tree cache file; the reference has only a stub for it (src/___SlimKDT_.zig:266-269)."""
+        rd = (C.c_uint8 * 3)(*[int(x) for x in self.root_dim])
+        capi.check(capi.lib().vr_save_kdt(os.fsencode(os.fspath(file_name)), self.nodes.ctypes.data, len(self.nodes), rd),
+                   "vr_save_kdt")
+
+    @staticmethod
+    def loadFromFile(file_name):
+        L = capi.lib()
+        p = C.POINTER(C.c_uint32)()
+        n = C.c_uint64()
+        rd = (C.c_uint8 * 3)()
+        capi.check(L.vr_load_kdt(os.fsencode(os.fspath(file_name)), C.byref(p), C.byref(n), rd), "vr_load_kdt")
+        nodes = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+        L.vr_free(p)
+        return SlimKDT(nodes, np.array(list(rd), dtype=np.uint8))
 
     @staticmethod
     def left(i):
