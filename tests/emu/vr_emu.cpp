@@ -101,3 +101,81 @@ extern "C" uint64_t vr_emu_div_check(uint64_t samples, uint64_t seed)
     }
     return bad;
 }
+
+/* The iso sweep with traversals shared between iso values, as the sweep kernel does it, one pixel at a
+ * time: trace the lowest open iso value while tracking the largest iso value with the same walk, give
+ * the result to the whole interval, go on behind it.  `chunk` cuts the iso range into independent
+ * pieces as the kernel does for load balance (0 = one piece).  Outputs are [iso_count][height][width]. */
+extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], const float src[3],
+                            const float forw[3], const float up[3], uint32_t width, uint32_t height, float viewport_width,
+                            uint32_t iso_begin, uint32_t iso_count, uint32_t chunk, uint32_t max_trips, uint8_t *gray,
+                            uint32_t *cell_flag, float *t_out, uint32_t *checked, uint32_t *node, uint64_t *sums /*[iso_count][7]*/,
+                            uint64_t *traces_out)
+{
+    VrViewK k;
+    k.ox = src[0]; k.oy = src[1]; k.oz = src[2];
+    k.fx = forw[0]; k.fy = forw[1]; k.fz = forw[2];
+    k.ux = up[0]; k.uy = up[1]; k.uz = up[2];
+    k.rx = k.fy * k.uz - k.fz * k.uy;
+    k.ry = k.fz * k.ux - k.fx * k.uz;
+    k.rz = k.fx * k.uy - k.fy * k.ux;
+    k.pixel_size = viewport_width / (float)width;
+    k.half_w = (float)(width / 2);
+    k.half_h = (float)(height / 2);
+    k.width = width; k.height = height;
+    k.rdx = root_dim[0]; k.rdy = root_dim[1]; k.rdz = root_dim[2];
+    k.root_hi = vr_pack10(k.rdx, k.rdy, k.rdz);
+    k.n_slots = n_slots;
+    std::memset(sums, 0, (size_t)iso_count * 7 * sizeof(uint64_t));
+    const uint64_t frame = (uint64_t)width * height;
+    if (chunk == 0) chunk = iso_count;
+    uint64_t traces = 0;
+    for (uint32_t yi = 0; yi < height; yi++)
+        for (uint32_t xi = 0; xi < width; xi++) {
+            const uint64_t pix = (uint64_t)yi * width + xi;
+            VrRay ray = vr_make_ray(k, xi, yi);
+            if (ray.oob) {
+                for (uint32_t j = 0; j < iso_count; j++) {
+                    gray[j * frame + pix] = 0; cell_flag[j * frame + pix] = 2u << 24; t_out[j * frame + pix] = 0.0f;
+                    checked[j * frame + pix] = 0; node[j * frame + pix] = 0; sums[j * 7 + 3]++;
+                }
+                continue;
+            }
+            HostStack st;
+            VrLane L;
+            vr_lane_begin(L, st, k, ray.dx, ray.dy, ray.dz, ray.t);
+            const uint32_t cell0 = L.cell;
+            for (uint32_t c0 = 0; c0 < iso_count; c0 += chunk) {
+                const uint32_t last = iso_begin + (c0 + chunk < iso_count ? c0 + chunk : iso_count) - 1u;
+                for (uint32_t iso = iso_begin + c0; iso <= last;) {
+                    vr_lane_restart(L, st, k, ray.t, cell0);
+                    VrIsoUpper track;
+                    track.upper = 255u;
+                    uint32_t moves = 0, esc = 0, flag = 0;
+                    for (;;) {
+                        const uint32_t go = vr_lane_descend(L, iso, HostFetch{ nodes }, st, max_trips, track);
+                        if (go == VR_GO_MORE) continue;
+                        if (go == VR_GO_HIT) { flag = 1; break; }
+                        moves++;
+                        if (!vr_lane_move(L, k, esc)) break;
+                        while (!vr_lane_pop(L, st, max_trips)) {}
+                    }
+                    traces++;
+                    const uint32_t e = track.upper < last ? track.upper : last;
+                    for (uint32_t i = iso; i <= e; i++) {
+                        const uint32_t j = i - iso_begin;
+                        gray[j * frame + pix] = flag ? vr_shade(L.t) : 0;
+                        cell_flag[j * frame + pix] = (flag ? vr_unpack_cell(L.cell) : 0u) | (flag << 24);
+                        t_out[j * frame + pix] = L.t;
+                        checked[j * frame + pix] = L.checked;
+                        node[j * frame + pix] = flag ? L.g - 1u : 0u;
+                        sums[j * 7 + 0] += L.checked; sums[j * 7 + 1] += flag; sums[j * 7 + 2] += 1u - flag;
+                        sums[j * 7 + 4] += esc; sums[j * 7 + 5] += moves;
+                    }
+                    iso = e + 1u;
+                }
+            }
+        }
+    if (traces_out) *traces_out = traces;
+    return 0;
+}

@@ -69,3 +69,40 @@ def test_axis_parallel_rays_are_oob(oracle, emu_lib):
     got = emu_render(emu_lib, 3, nodes, rd, pos, forw, up, 9, 9, 0.02, 100)
     assert_same_render(got, ref, "axis-parallel")
     assert (ref["cell_flag"][4, 4] >> 24) == 2  # the centre ray is exactly axis-parallel
+
+
+@pytest.mark.parametrize("chunk", [0, 32, 7])
+def test_shared_traversals_across_iso_values_equal_one_render_per_iso(oracle, emu_lib, c60_vox, c60_tree, chunk):
+    """The sweep kernel traces a ray once per interval of iso values that cannot change any test outcome;
+    every per-iso output must still equal the oracle's separate render of that iso value, bit for bit."""
+    from helpers import emu_sweep
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    W = H = 40
+    got = emu_sweep(emu_lib, nodes, rd, pos, forw, up, W, H, 2.0, 0, 256, chunk=chunk, max_trips=6)
+    n_active = 0
+    for iso in range(256):
+        ref = oracle.render(nodes, rd, pos, forw, up, W, H, 2.0, iso)
+        assert (got["gray"][iso] == ref["rgb"][..., 0]).all(), iso
+        assert (got["cell_flag"][iso] == ref["cell_flag"]).all(), iso
+        assert (got["t"][iso].view(np.uint32) == ref["t"].view(np.uint32)).all(), iso
+        assert (got["checked"][iso] == ref["checked"]).all() and (got["node"][iso] == ref["node"]).all(), iso
+        st = ref["stats"]
+        assert tuple(int(x) for x in got["sums"][iso][:6]) == (st.nodes_checked, st.hit_count, st.miss_count, st.oob_count,
+                                                              st.escape_help_events, st.moves), iso
+        n_active = W * H - st.oob_count
+    assert got["traces"] < 256 * n_active / 3  # the sharing is real: far fewer traversals than ray x iso pairs
+
+
+def test_shared_traversals_on_noise_and_partial_ranges(oracle, emu_lib):
+    from helpers import emu_sweep
+    rng = np.random.default_rng(8)
+    vox = random_volume(rng, (9, 12, 7), "noise")
+    nodes, rd, _ = oracle.build_kdt(vox, "AlwaysCenter")
+    pos, forw, up = oracle.main_camera(vox.shape, (50.0, -120.0, 30.0))
+    for b, n, chunk in [(0, 256, 0), (17, 100, 16), (255, 1, 0), (200, 56, 5)]:
+        got = emu_sweep(emu_lib, nodes, rd, pos, forw, up, 24, 16, 0.15, b, n, chunk=chunk)
+        for j in range(n):
+            ref = oracle.render(nodes, rd, pos, forw, up, 24, 16, 0.15, b + j)
+            assert (got["gray"][j] == ref["rgb"][..., 0]).all() and (got["checked"][j] == ref["checked"]).all(), (b, j)
+            assert (got["t"][j].view(np.uint32) == ref["t"].view(np.uint32)).all(), (b, j)

@@ -318,15 +318,45 @@ VR_HD bool vr_node_holds(uint32_t n, uint32_t iso) { return (n & 0xffu) <= iso &
  * (src/raytrace.zig:161-194, zoom: src/SlimKDT.zig:90-103), at most `max_trips` levels per call.
  * A wave runs a loop as long as its slowest lane; bounding the trips and letting the few long
  * descents continue in the next round keeps the lanes of a wave busy. */
-template <class Fetch, class Stack>
-VR_HD uint32_t vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stack &stack, uint32_t max_trips)
+/* What a traversal learns about OTHER iso values.  The walk of a ray depends on the iso value only
+ * through the outcomes of the density-range tests at the nodes it visits; every iso value that gives
+ * the same outcome at every one of them gives the same walk: same MOVE points, same `t` bits, same
+ * hit cell, same reference-defined check count.  A sweep that goes through the iso values in rising
+ * order therefore only needs the largest such value: `upper` starts at 255 and shrinks to
+ *   max      at a node whose range [min, max] holds the iso value,
+ *   min - 1  at a node excluded because the iso value is below its range
+ * (a node excluded from above stays excluded for every larger iso value).
+ * VrNoIsoTrack is the no-op used where one iso value is rendered at a time. */
+struct VrNoIsoTrack {
+    VR_HD void passed(uint32_t) {}
+    VR_HD void excluded(uint32_t, uint32_t) {}
+};
+struct VrIsoUpper {
+    uint32_t upper;
+    VR_HD void passed(uint32_t n)
+    {
+        const uint32_t mx = (n >> 8) & 0xffu;
+        upper = mx < upper ? mx : upper;
+    }
+    VR_HD void excluded(uint32_t n, uint32_t iso)
+    {
+        const uint32_t mn = n & 0xffu;
+        const uint32_t lim = iso < mn ? mn - 1u : 255u;
+        upper = lim < upper ? lim : upper;
+    }
+};
+
+template <class Fetch, class Stack, class Track>
+VR_HD uint32_t vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stack &stack, uint32_t max_trips, Track &track)
 {
     const uint32_t d0 = stack.depth();
     uint32_t out = VR_GO_MORE;
     for (uint32_t trip = 0; trip < max_trips; trip++) {
         const uint32_t n = fetch(L.g);
         const bool holds = vr_node_holds(n, iso);
-        if (!holds || (n & VR_N_LEAF)) { out = holds ? VR_GO_HIT : VR_GO_EXCLUDED; break; }
+        if (!holds) { track.excluded(n, iso); out = VR_GO_EXCLUDED; break; }
+        track.passed(n);
+        if (n & VR_N_LEAF) { out = VR_GO_HIT; break; }
         const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
         const bool right = ((L.cell >> sh) & 0xffu) >= part;
         uint32_t side = right ? L.lo : L.hi;
@@ -339,6 +369,25 @@ VR_HD uint32_t vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stac
     /* one check per node tested (src/raytrace.zig:162): every level passed, plus the node that ended the descent */
     L.checked += stack.depth() - d0 + (out != VR_GO_MORE ? 1u : 0u);
     return out;
+}
+
+template <class Fetch, class Stack>
+VR_HD uint32_t vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stack &stack, uint32_t max_trips)
+{
+    VrNoIsoTrack none;
+    return vr_lane_descend(L, iso, fetch, stack, max_trips, none);
+}
+
+/* Puts a lane back at the entry point of its ray (for the next iso value of a sweep): everything
+ * vr_lane_begin derives from the direction alone is kept. */
+template <class Stack>
+VR_HD void vr_lane_restart(VrLane &L, Stack &stack, const VrViewK &v, float t_entry, uint32_t cell_entry)
+{
+    L.t = t_entry;
+    L.cell = cell_entry;
+    L.lo = 0; L.hi = v.root_hi;
+    L.g = 1; L.checked = 0;
+    stack.reset();
 }
 
 /* MOVE (src/raytrace.zig:199-205) + escape help (:233-242).  Returns false when the new point is
