@@ -13,7 +13,8 @@ from helpers import assert_same_render, random_volume
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [capi.KERNEL_RESTART_GLOBAL, capi.KERNEL_RESTART_LDS, capi.KERNEL_RESUME, capi.KERNEL_PIPELINE]
+VARIANTS = [capi.KERNEL_RESTART_GLOBAL, capi.KERNEL_RESTART_LDS, capi.KERNEL_RESUME, capi.KERNEL_PIPELINE,
+            capi.KERNEL_SWEEP]
 
 
 @pytest.fixture(scope="module")
@@ -318,6 +319,52 @@ def test_skull_4096_row_shards_equal_whole_frame(oracle, skull_vox, skull_tree, 
     assert stats[3] == ws["oob_count"] and ws["hit_count"] + ws["miss_count"] + ws["oob_count"] == W * H
     band = oracle.render(nodes, rd, pos, forw, up, W, H, 2.0, 80, rows=(2040, 2072), taps=False)
     assert (band["rgb"][2040:2072] == whole["rgb"][0, 2040:2072]).all()
+
+
+def test_sweep_kernel_every_iso_value_matches_oracle(oracle, c60_vox, c60_tree, c60_renderer, skull_vox, skull_tree,
+                                                     skull_renderer):
+    """The sweep kernel shares one traversal between all iso values that cannot change a test outcome on the
+    way.  Every per-iso output -- pixels, hit cell, t bits, hit leaf, reference-defined check count, counters --
+    must equal the oracle's separate render of that iso value: all 256 iso values on C60, a block on Skull,
+    and iso ranges that do not start at 0 or end at 255."""
+    for vox, tree, rnd, W, H, b, n in [(c60_vox, c60_tree, c60_renderer, 96, 80, 0, 256),
+                                       (skull_vox, skull_tree, skull_renderer, 160, 128, 60, 40),
+                                       (c60_vox, c60_tree, c60_renderer, 33, 47, 251, 5),
+                                       (c60_vox, c60_tree, c60_renderer, 64, 64, 100, 1)]:
+        nodes, rd, _ = tree
+        pos, forw, up = oracle.main_camera(vox.shape)
+        rnd.set_kernel(capi.KERNEL_SWEEP)
+        out = rnd.renderSweep(pos, forw, up, W, H, 2.0, b, n, taps=True)
+        rnd.set_kernel(capi.KERNEL_DEFAULT)
+        for j in range(n):
+            ref = oracle.render(nodes, rd, pos, forw, up, W, H, 2.0, b + j)
+            got = {"rgb": out["rgb"][j], "cell_flag": out["cell_flag"][j], "t": out["t"][j], "checked": out["checked"][j],
+                   "node": out["node"][j], "stats": out["stats"][j]}
+            assert_same_render(got, ref, "sweep kernel iso %d" % (b + j))
+            _check_stats(got, ref)
+
+
+def test_sweep_kernel_equals_per_iso_kernel_at_full_size(oracle, skull_vox, skull_renderer):
+    """Skull 1024^2, all 256 iso values: frames and counters of the sweep kernel and of the one-traversal-per-iso
+    kernel are identical."""
+    import torch
+    pos, forw, up = oracle.main_camera(skull_vox.shape)
+    L = capi.lib()
+    W = H = 1024
+    v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+    res = []
+    for variant in (capi.KERNEL_PIPELINE, capi.KERNEL_SWEEP):
+        skull_renderer.set_kernel(variant)
+        d_rgb = torch.empty((256, H, W, 3), dtype=torch.uint8, device="cuda")
+        d_stats = torch.zeros((256, 7), dtype=torch.int64, device="cuda")
+        capi.check(L.vr_render_device(skull_renderer.handle, C.byref(v), 0, 256, 0, H, d_rgb.data_ptr(), d_stats.data_ptr(),
+                                      None, None), "vr_render_device")
+        capi.check(L.vr_sync(skull_renderer.handle), "vr_sync")
+        res.append((d_rgb, d_stats.cpu().numpy()))
+    skull_renderer.set_kernel(capi.KERNEL_DEFAULT)
+    assert (res[0][1] == res[1][1]).all()
+    assert int(res[0][1][:, 0].sum()) == 8519971365 and int(res[0][1][:, 6].sum()) == 0
+    assert bool(torch.equal(res[0][0], res[1][0]))
 
 
 def test_vr_bench_driver_reproduces_reference_renders(tmp_path, golden_gray):

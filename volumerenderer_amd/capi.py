@@ -15,7 +15,7 @@ VR_ETREE = -8
 VR_EHIP_BASE = -1000
 FLAG_MISS, FLAG_HIT, FLAG_OOB = 0, 1, 2
 
-KERNEL_DEFAULT, KERNEL_RESTART_GLOBAL, KERNEL_RESTART_LDS, KERNEL_RESUME, KERNEL_PIPELINE = 0, 1, 2, 3, 4
+KERNEL_DEFAULT, KERNEL_RESTART_GLOBAL, KERNEL_RESTART_LDS, KERNEL_RESUME, KERNEL_PIPELINE, KERNEL_SWEEP = 0, 1, 2, 3, 4, 5
 
 HEURISTICS = {
     "AlwaysCenter": 0,

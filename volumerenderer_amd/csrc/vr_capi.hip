@@ -282,8 +282,8 @@ int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_
         taps.checked = d_taps->checked;
         taps.node = d_taps->node;
     }
-    const int variant = c->variant == VR_KERNEL_DEFAULT ? VR_KERNEL_PIPELINE : c->variant;
-    if (variant == VR_KERNEL_PIPELINE) {
+    const int variant = c->variant;
+    if (variant == VR_KERNEL_DEFAULT || variant == VR_KERNEL_PIPELINE || variant == VR_KERNEL_SWEEP) {
         /* growing the scratch is the only allocation on this path; it happens when a larger view comes */
         const size_t need = vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count);
         if (need > c->work_cap) VR_HIP(hipStreamSynchronize(s));
@@ -399,6 +399,7 @@ const char *vr_kernel_name(int variant)
     case VR_KERNEL_RESTART_LDS: return "restart-lds";
     case VR_KERNEL_RESUME: return "resume";
     case VR_KERNEL_PIPELINE: return "pipeline";
+    case VR_KERNEL_SWEEP: return "sweep";
     default: return nullptr;
     }
 }

@@ -21,8 +21,11 @@ enum {
     VR_KERNEL_RESTART_GLOBAL = 1, /* literal root-restart loop, every node read from global memory     */
     VR_KERNEL_RESTART_LDS = 2,    /* root-restart loop, top tree levels staged in LDS                  */
     VR_KERNEL_RESUME = 3,         /* per-pixel threads, path stack in LDS, resume after a MOVE         */
-    VR_KERNEL_PIPELINE = 4,       /* compacted ray list + persistent waves with lane refill (default)  */
-    VR_KERNEL_COUNT = 5
+    VR_KERNEL_PIPELINE = 4,       /* compacted ray list + persistent waves with lane refill, one       */
+                                  /* traversal per ray and iso value (default for a single iso value)  */
+    VR_KERNEL_SWEEP = 5,          /* the same machinery with traversals shared between iso values      */
+                                  /* (default for more than one iso value)                             */
+    VR_KERNEL_COUNT = 6
 };
 
 /* Device scratch the pipeline variant needs for one call (ray list, tile offsets, queue heads). */

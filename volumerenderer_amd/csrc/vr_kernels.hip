@@ -527,6 +527,187 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
 #endif
 }
 
+/* --------------------------------------------------------- pipeline: iso sweep kernel ---- */
+
+/* The sweep over iso values with traversals shared between them.  A lane owns one ray and a block of iso
+ * values; it traces the lowest open iso value while tracking the largest iso value that cannot change
+ * the outcome of any density-range test on the way (VrIsoUpper), gives the result to every iso value up
+ * to there -- pixels, taps and counters are exactly those of a separate traversal per iso value -- and
+ * goes on behind it.  On the Skull sweep a ray has 28 distinct traversals in 256 iso values.
+ *
+ * Work items are (ray, iso block) pairs from one queue; the iso range is cut into as many blocks as it
+ * takes to have several items per lane of the grid (a ray's 256 iso values cost between 5 and >100
+ * traversals, so whole rays would balance badly when there are about as many rays as lanes).
+ *
+ * Per-iso counters go through difference arrays in LDS: +x at the first iso value of an interval, -x
+ * behind its last; a prefix sum per block at the end, then one global atomic per iso value and counter. */
+#ifndef VR_SWEEP_ITEMS_PER_LANE
+#define VR_SWEEP_ITEMS_PER_LANE 6
+#endif
+#ifndef VR_SWEEP_MAX_BLOCKS
+#define VR_SWEEP_MAX_BLOCKS 32
+#endif
+constexpr uint32_t kSweepCounters = 5; /* hit, miss, moves, escape help, errors (u32 each); checks are u64 */
+
+__host__ __device__ __forceinline__ uint32_t sweep_stat_words(uint32_t iso_count)
+{
+    return (2u + kSweepCounters) * (iso_count + 1u) + ((2u + kSweepCounters) * (iso_count + 1u) & 1u);
+}
+
+template <bool TAPS>
+__global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top,
+                                                            uint32_t stack_rows,
+                                                            const float4 *__restrict__ ray_dt,
+                                                            const uint32_t *__restrict__ ray_pix,
+                                                            const uint32_t *__restrict__ n_active_ptr,
+                                                            uint32_t *__restrict__ head, uint32_t iso_begin,
+                                                            uint32_t iso_count, uint64_t frame_pixels,
+                                                            uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
+                                                            VrTapsK taps)
+{
+    /* dynamic LDS: [path stacks][check sums: (iso_count + 1) x u64][counters: 5 x (iso_count + 1) x u32][top node words] */
+    extern __shared__ uint32_t s_dyn[];
+    unsigned long long *s_checks = (unsigned long long *)(s_dyn + stack_rows * kTraceThreads);
+    uint32_t *s_cnt = (uint32_t *)(s_checks + (iso_count + 1u));
+    uint32_t *s_top = s_dyn + stack_rows * kTraceThreads + sweep_stat_words(iso_count);
+    const uint32_t n_k = iso_count + 1u;
+    for (uint32_t i = threadIdx.x; i < sweep_stat_words(iso_count); i += kTraceThreads) s_dyn[stack_rows * kTraceThreads + i] = 0u;
+    for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_top[i] = nodes[i];
+    __syncthreads();
+    LdsStack<kTraceThreads> stack;
+    const TopFetch fetch(nodes, s_top, n_top);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_active = *n_active_ptr;
+    /* iso blocks: enough (ray, block) items for several per lane of the grid */
+    const uint64_t want = (uint64_t)gridDim.x * kTraceThreads * VR_SWEEP_ITEMS_PER_LANE;
+    uint32_t n_blocks = (uint32_t)((want + n_active - 1u) / (n_active ? n_active : 1u));
+    n_blocks = n_blocks < 1u ? 1u : (n_blocks > VR_SWEEP_MAX_BLOCKS ? VR_SWEEP_MAX_BLOCKS : n_blocks);
+    n_blocks = n_blocks > iso_count ? iso_count : n_blocks;
+    const uint32_t block_isos = (iso_count + n_blocks - 1u) / n_blocks;
+    n_blocks = (iso_count + block_isos - 1u) / block_isos;
+    const uint32_t n_items = n_active * n_blocks; /* n_blocks > 1 only while n_active is far below 2^32 / 32 */
+    const uint64_t frame_bytes = frame_pixels * 3u;
+
+    VrLane L;
+    VrIsoUpper track;
+    track.upper = 255u;
+    uint32_t pix = 0, iso = 0, iso_last = 0, cell0 = 0, moves = 0, esc = 0;
+    float t0 = 0.0f;
+    bool alive = false, exhausted = false, popping = false;
+
+    for (;;) {
+        /* ---- refill idle lanes from the item queue ---- */
+        const unsigned long long idle = __ballot(!alive);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (!exhausted && n_idle >= kRefillMin) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(head, n_idle);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!alive && mine < n_items) {
+#if defined(VR_SWEEP_BLOCK_MAJOR)
+                const uint32_t blk = mine / n_active, ray = mine - blk * n_active;
+#else
+                const uint32_t ray = mine / n_blocks, blk = mine - ray * n_blocks; /* the blocks of one ray side by side */
+#endif
+                const float4 r = ray_dt[ray];
+                pix = ray_pix[ray];
+                vr_lane_begin(L, stack, v, r.x, r.y, r.z, r.w);
+                t0 = r.w;
+                cell0 = L.cell;
+                iso = iso_begin + blk * block_isos;
+                iso_last = iso_begin + (blk * block_isos + block_isos < iso_count ? blk * block_isos + block_isos : iso_count) - 1u;
+                track.upper = 255u;
+                moves = 0; esc = 0;
+                alive = true;
+                popping = false;
+            }
+            exhausted = (uint64_t)base + n_idle >= n_items;
+        }
+        if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
+
+        if (alive) {
+            uint32_t go = VR_GO_MORE;
+            /* ---- descend while the node's density range holds the iso value (bounded) ---- */
+            if (!popping) go = vr_lane_descend(L, iso, fetch, stack, kDescendTrips, track);
+            bool done = false, hit = false;
+            uint32_t err = 0;
+            if (go == VR_GO_HIT) {
+                done = true; hit = true;
+            } else if (go == VR_GO_EXCLUDED) {
+                moves++;
+                bool in_root = vr_lane_move(L, v, esc);
+                if (L.checked > VR_MAX_CHECKED) { in_root = false; err = 1; }
+                if (in_root) popping = true; else done = true; /* left the volume: a miss (src/raytrace.zig:66-68) */
+            }
+            /* ---- pop to the lowest ancestor that holds the new point (bounded) ---- */
+            if (popping && !done) popping = !vr_lane_pop(L, stack, kPopTrips);
+
+            if (done) {
+                /* ---- the traversal stands for every iso value from `iso` to `e` ---- */
+                const uint32_t e = track.upper < iso_last ? track.upper : iso_last;
+                const uint32_t k0 = iso - iso_begin, k1 = e + 1u - iso_begin;
+                atomicAdd(&s_checks[k0], (unsigned long long)L.checked);
+                atomicAdd(&s_checks[k1], 0ull - (unsigned long long)L.checked);
+                uint32_t *c = s_cnt + (hit ? 0u : n_k);
+                atomicAdd(&c[k0], 1u); atomicAdd(&c[k1], 0u - 1u);
+                if (moves) { atomicAdd(&s_cnt[2u * n_k + k0], moves); atomicAdd(&s_cnt[2u * n_k + k1], 0u - moves); }
+                if (esc) { atomicAdd(&s_cnt[3u * n_k + k0], esc); atomicAdd(&s_cnt[3u * n_k + k1], 0u - esc); }
+                if (err) { atomicAdd(&s_cnt[4u * n_k + k0], 1u); atomicAdd(&s_cnt[4u * n_k + k1], 0u - 1u); }
+                if (hit) { /* shade and store (src/raytrace.zig:56-61), one frame per iso value */
+                    const uint8_t g = vr_shade(L.t);
+                    uint8_t *p = rgb + (uint64_t)k0 * frame_bytes + (uint64_t)pix * 3u;
+                    for (uint32_t k = k0; k < k1; k++, p += frame_bytes) { p[0] = g; p[1] = g; p[2] = g; }
+                }
+                if (TAPS) {
+                    const uint32_t cf = hit ? (vr_unpack_cell(L.cell) | (VR_FLAG_HIT << 24)) : (VR_FLAG_MISS << 24);
+                    const uint32_t nd = hit ? L.g - 1u : 0u;
+                    for (uint32_t k = k0; k < k1; k++) {
+                        const uint64_t at = (uint64_t)k * frame_pixels + pix;
+                        if (taps.cell_flag) taps.cell_flag[at] = cf;
+                        if (taps.node) taps.node[at] = nd;
+                        if (taps.t) taps.t[at] = L.t;
+                        if (taps.checked) taps.checked[at] = L.checked;
+                    }
+                }
+                iso = e + 1u;
+                if (iso > iso_last) {
+                    alive = false;
+                } else { /* same ray, next open iso value */
+                    vr_lane_restart(L, stack, v, t0, cell0);
+                    track.upper = 255u;
+                    moves = 0; esc = 0;
+                    popping = false;
+                }
+            }
+        }
+    }
+
+    /* ---- per-iso counters: prefix sums of the difference arrays, then one atomic per iso value and counter ---- */
+    __syncthreads();
+    if (threadIdx.x < kSweepCounters) {
+        uint32_t *c = s_cnt + threadIdx.x * n_k;
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < iso_count; k++) { run += c[k]; c[k] = run; }
+    } else if (threadIdx.x == kSweepCounters) {
+        unsigned long long run = 0;
+        for (uint32_t k = 0; k < iso_count; k++) { run += s_checks[k]; s_checks[k] = run; }
+    }
+    __syncthreads();
+    if (stats) {
+        for (uint32_t k = threadIdx.x; k < iso_count; k += kTraceThreads) {
+            vr_render_stats *s = stats + k;
+            add_stat(&s->nodes_checked, s_checks[k]);
+            add_stat(&s->hit_count, s_cnt[k]);
+            add_stat(&s->miss_count, s_cnt[n_k + k]);
+            add_stat(&s->moves, s_cnt[2u * n_k + k]);
+            add_stat(&s->escape_help_events, s_cnt[3u * n_k + k]);
+            add_stat(&s->errors, s_cnt[4u * n_k + k]);
+        }
+    }
+}
+
 } // namespace
 
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count)
@@ -552,12 +733,14 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     {
         /* the persistent kernel adds 32-bit offsets to the low word of the node array's address */
         const uintptr_t p = (uintptr_t)d_nodes_prepared, last = p + (view.n_slots + 1u) * sizeof(uint32_t) - 1u;
-        if (variant == VR_KERNEL_PIPELINE && (p >> 32) != (last >> 32)) variant = VR_KERNEL_RESUME;
+        const bool family = variant == VR_KERNEL_DEFAULT || variant == VR_KERNEL_PIPELINE || variant == VR_KERNEL_SWEEP;
+        if (family && (p >> 32) != (last >> 32)) variant = VR_KERNEL_RESUME;
     }
     const size_t stack_bytes = ((size_t)stack_levels + 1u) * 256u * sizeof(uint32_t); /* + the spare row above the root */
     hipError_t e;
 
-    if (variant != VR_KERNEL_PIPELINE) {
+    const bool use_default = variant == VR_KERNEL_DEFAULT;
+    if (!use_default && variant != VR_KERNEL_PIPELINE && variant != VR_KERNEL_SWEEP) {
         const uint32_t tiles_x = (view.width + kBlockW - 1) / kBlockW;
         const uint32_t tiles_y = (n_rows + kBlockH - 1) / kBlockH;
         dim3 grid(tiles_x * tiles_y, iso_count, 1), block(256, 1, 1);
@@ -610,23 +793,28 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     if ((e = hipGetLastError()) != hipSuccess) return e;
 
     /* persistent grid: kTraceBlocksPerCu blocks per CU.  A block's LDS holds the path stacks and, in what is
-     * left of its share of the CU's 160 KiB, the top K levels of the tree (two thirds of all node reads). */
+     * left of its share of the CU's 160 KiB, the top K levels of the tree (two thirds of all node reads).
+     * More than one iso value: the sweep kernel, which shares traversals between iso values. */
+    const bool sweep = variant == VR_KERNEL_SWEEP || (use_default && iso_count > 1u);
     const size_t lds_limit = 160u * 1024u / kTraceBlocksPerCu;
     const size_t trace_stack_bytes = ((size_t)stack_levels + 1u) * kTraceThreads * sizeof(uint32_t);
+    const size_t stat_bytes = sweep ? (size_t)sweep_stat_words(iso_count) * sizeof(uint32_t) : 0u;
     uint32_t top_levels = 14;
     if (const char *tune = getenv("VR_TUNE_TOP_LEVELS")) top_levels = (uint32_t)atoi(tune); /* experiment knob */
     if (top_levels > 14) top_levels = 14;
-    while (top_levels > 0 && ((((size_t)1 << top_levels) * sizeof(uint32_t)) + trace_stack_bytes > lds_limit ||
+    while (top_levels > 0 && ((((size_t)1 << top_levels) * sizeof(uint32_t)) + trace_stack_bytes + stat_bytes > lds_limit ||
                               ((uint64_t)1 << top_levels) > view.n_slots + 1u))
         top_levels--;
     const uint32_t n_top = 1u << top_levels; /* heap positions 0 .. 2^K - 1 = levels 0 .. K-1 (K = 0: the unused slot 0 only) */
-    const size_t trace_lds = (size_t)n_top * sizeof(uint32_t) + trace_stack_bytes;
+    const size_t trace_lds = (size_t)n_top * sizeof(uint32_t) + trace_stack_bytes + stat_bytes;
     if (trace_lds > lds_limit) return hipErrorInvalidValue;
-    const void *fn = any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>;
-    static bool lds_set[2] = { false, false };
-    if (!lds_set[any_tap ? 1 : 0]) {
-        if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit)) != hipSuccess) return e;
-        lds_set[any_tap ? 1 : 0] = true;
+    const int fn_id = (sweep ? 2 : 0) + (any_tap ? 1 : 0);
+    const void *fn = sweep ? (any_tap ? (const void *)vr_k_sweep<true> : (const void *)vr_k_sweep<false>)
+                           : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
+    static bool lds_set[4] = { false, false, false, false };
+    if (!lds_set[fn_id]) {
+        if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u))) != hipSuccess) return e;
+        lds_set[fn_id] = true;
     }
     const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
     const uint64_t frame_pixels = n_pix;
