@@ -115,7 +115,7 @@ def profile_counters():
     """VALU figures of the committed counter pass (profiles/r01_pmc_summary.json), for the default workload."""
     try:
         s = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        k = [v for n, v in s.items() if "vr_k_trace" in n][0]
+        k = [v for n, v in s.items() if "vr_k_sweep" in n][0]
         simd_quanta = k["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0  # cycles per XCD / 4-cycle issue slots x 1024 SIMDs
         return {"valu_busy_frac": k["SQ_ACTIVE_INST_VALU"] / simd_quanta,
                 "valu_lane_util_frac": k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"]),
@@ -260,7 +260,7 @@ def main():
                        "kernel": capi.lib().vr_kernel_name(args.kernel).decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "vr_k_trace" if args.kernel in (0, 4) else "vr_k_render", "kernel_ms": kernel_ms, "launches_timed": int(launches.value),
+                         "kernel": {0: "vr_k_sweep", 4: "vr_k_trace", 5: "vr_k_sweep"}.get(args.kernel, "vr_k_render"), "kernel_ms": kernel_ms, "launches_timed": int(launches.value),
                          "algorithmic_bytes_per_launch": alg_bytes, "nodes_checked_per_launch": nodes_checked,
                          "measured_copy_GBps": copy_ceiling_gbps(torch),
                          "counters": profile_counters() if (args.volume == "skull" and W == 1024) else None},

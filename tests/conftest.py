@@ -6,6 +6,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # PyTorch ships its own HIP runtime: load it before libvr_hip.so pulls in the system one, whatever tests are selected
+    import torch  # noqa: F401
+except ImportError:
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

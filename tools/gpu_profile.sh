@@ -26,6 +26,6 @@ for f in glob.glob("$R/$out/pmc*/**/*counter_collection.csv", recursive=True):
 summary={k:{c:sum(v)/len(v) for c,v in d.items()} for k,d in agg.items()}
 json.dump(summary, open("$R/$out/pmc_summary.json","w"), indent=1)
 for k,d in summary.items():
-    if 'vr_k_trace' in k or 'vr_k_render' in k:
+    if 'vr_k_trace' in k or 'vr_k_render' in k or 'vr_k_sweep' in k:
         for c in sorted(d): print("%-36s %.5g" % (c, d[c]))
 PY

@@ -311,14 +311,15 @@ __global__ void vr_k_tap_defaults(VrTapsK taps, uint64_t n)
 
 /* --------------------------------------------------------- pipeline: persistent trace ---- */
 
-#ifdef VR_DIAG /* diagnostic build only: where a wave's cycles go (never compiled into the product library) */
-__device__ unsigned long long g_diag[20];
 __device__ __forceinline__ uint32_t wave_max(uint32_t x)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { uint32_t y = __shfl_xor(x, off, 64); x = y > x ? y : x; }
     return x;
 }
+#ifdef VR_DIAG /* diagnostic build only: where a wave's cycles go (never compiled into the product library) */
+__device__ unsigned long long g_diag[20];
+__device__ unsigned long long g_wave_span[3 * 8192]; /* per wave: begin, queue empty, end (s_memrealtime) */
 #define DIAG_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define DIAG_ADD(i, val) d_acc[i] += (unsigned long long)(val)
 #else
@@ -542,11 +543,24 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
  * Per-iso counters go through difference arrays in LDS: +x at the first iso value of an interval, -x
  * behind its last; a prefix sum per block at the end, then one global atomic per iso value and counter. */
 #ifndef VR_SWEEP_ITEMS_PER_LANE
-#define VR_SWEEP_ITEMS_PER_LANE 6
+#define VR_SWEEP_ITEMS_PER_LANE 12
+#endif
+#ifndef VR_SWEEP_REFILL_MIN
+#define VR_SWEEP_REFILL_MIN 16
 #endif
 #ifndef VR_SWEEP_MAX_BLOCKS
 #define VR_SWEEP_MAX_BLOCKS 32
 #endif
+#ifndef VR_SWEEP_STEALS
+#define VR_SWEEP_STEALS 2
+#endif
+#ifndef VR_SWEEP_STEAL_MIN
+#define VR_SWEEP_STEAL_MIN 2
+#endif
+/* once the queue is empty: hand-overs of half an iso range to an idle lane per wave and round, and the
+ * shortest range (iso values behind the current one) worth splitting */
+constexpr uint32_t kSweepSteals = VR_SWEEP_STEALS, kSweepStealMin = VR_SWEEP_STEAL_MIN;
+constexpr uint32_t kSweepRefillMin = VR_SWEEP_REFILL_MIN; /* items last long here: refills are rare */
 constexpr uint32_t kSweepCounters = 5; /* hit, miss, moves, escape help, errors (u32 each); checks are u64 */
 
 __host__ __device__ __forceinline__ uint32_t sweep_stat_words(uint32_t iso_count)
@@ -579,16 +593,23 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_active = *n_active_ptr;
-    /* iso blocks: enough (ray, block) items for several per lane of the grid */
+    /* iso blocks: enough (ray, block) items for several per lane of the grid.  Items are numbered group by
+     * group of 64 consecutive rays (one tile of the image): the 64 rays on the first iso block, the same rays
+     * on the next block, ... */
     const uint64_t want = (uint64_t)gridDim.x * kTraceThreads * VR_SWEEP_ITEMS_PER_LANE;
-    uint32_t n_blocks = (uint32_t)((want + n_active - 1u) / (n_active ? n_active : 1u));
-    n_blocks = n_blocks < 1u ? 1u : (n_blocks > VR_SWEEP_MAX_BLOCKS ? VR_SWEEP_MAX_BLOCKS : n_blocks);
-    n_blocks = n_blocks > iso_count ? iso_count : n_blocks;
-    const uint32_t block_isos = (iso_count + n_blocks - 1u) / n_blocks;
-    n_blocks = (iso_count + block_isos - 1u) / block_isos;
-    const uint32_t n_items = n_active * n_blocks; /* n_blocks > 1 only while n_active is far below 2^32 / 32 */
+    uint32_t nb = (uint32_t)((want + n_active - 1u) / (n_active ? n_active : 1u));
+    nb = nb < 1u ? 1u : (nb > VR_SWEEP_MAX_BLOCKS ? VR_SWEEP_MAX_BLOCKS : nb);
+    nb = nb > iso_count ? iso_count : nb;
+    const uint32_t block_isos = (iso_count + nb - 1u) / nb, n_blocks = (iso_count + block_isos - 1u) / block_isos;
+    const uint32_t n_items = ((n_active + 63u) & ~63u) * n_blocks; /* more than one block only while n_active is far below 2^32 / 64 */
     const uint64_t frame_bytes = frame_pixels * 3u;
 
+#ifdef VR_DIAG
+    unsigned long long d_acc[20] = { 0 };
+    const unsigned long long d_begin = __builtin_amdgcn_s_memtime(), d_rbegin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long d_exh = 0, d_rexh = 0;
+    uint32_t d_lane_traces = 0, d_lane_emit = 0;
+#endif
     VrLane L;
     VrIsoUpper track;
     track.upper = 255u;
@@ -600,19 +621,16 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
         /* ---- refill idle lanes from the item queue ---- */
         const unsigned long long idle = __ballot(!alive);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (!exhausted && n_idle >= kRefillMin) {
+        if (!exhausted && n_idle >= kSweepRefillMin) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(head, n_idle);
             base = __builtin_amdgcn_readfirstlane(base);
             const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (!alive && mine < n_items) {
-#if defined(VR_SWEEP_BLOCK_MAJOR)
-                const uint32_t blk = mine / n_active, ray = mine - blk * n_active;
-#else
-                const uint32_t ray = mine / n_blocks, blk = mine - ray * n_blocks; /* the blocks of one ray side by side */
-#endif
-                const float4 r = ray_dt[ray];
-                pix = ray_pix[ray];
+                const uint32_t grp = mine / (64u * n_blocks), in = mine - grp * 64u * n_blocks;
+                const uint32_t blk = in >> 6, ray = grp * 64u + (in & 63u);
+                const float4 r = ray_dt[ray < n_active ? ray : 0u];
+                pix = ray_pix[ray < n_active ? ray : 0u];
                 vr_lane_begin(L, stack, v, r.x, r.y, r.z, r.w);
                 t0 = r.w;
                 cell0 = L.cell;
@@ -620,12 +638,60 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 iso_last = iso_begin + (blk * block_isos + block_isos < iso_count ? blk * block_isos + block_isos : iso_count) - 1u;
                 track.upper = 255u;
                 moves = 0; esc = 0;
-                alive = true;
+                alive = ray < n_active; /* the last group of 64 may be short */
                 popping = false;
             }
             exhausted = (uint64_t)base + n_idle >= n_items;
+#ifdef VR_DIAG
+            if (exhausted && !d_exh) { d_exh = __builtin_amdgcn_s_memtime(); d_rexh = __builtin_amdgcn_s_memrealtime(); }
+#endif
         }
         if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
+        /* ---- queue empty: idle lanes take over the upper half of the longest iso range left in the wave ---- */
+        if (exhausted) {
+#pragma unroll 1
+            for (uint32_t steal = 0; steal < kSweepSteals; steal++) {
+                const unsigned long long idle_now = __ballot(!alive);
+                if (idle_now == 0ull) break;
+                const uint32_t rem = alive ? iso_last - iso : 0u; /* iso values behind the one being traced */
+                const uint32_t best = wave_max((rem << 6) | lane);
+                if ((best >> 6) < kSweepStealMin) break;
+                const uint32_t victim = __builtin_amdgcn_readfirstlane(best & 63u);
+                const uint32_t thief = (uint32_t)__ffsll((long long)idle_now) - 1u;
+                /* the victim's ray, read by every lane, kept by the thief */
+                const float s_dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.dx), victim));
+                const float s_dy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.dy), victim));
+                const float s_dz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.dz), victim));
+                const float s_rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.rx), victim));
+                const float s_ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.ry), victim));
+                const float s_rz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.rz), victim));
+                const float s_t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t0), victim));
+                const uint32_t s_pm = (uint32_t)__builtin_amdgcn_readlane((int)L.posmask, victim);
+                const uint32_t s_c0 = (uint32_t)__builtin_amdgcn_readlane((int)cell0, victim);
+                const uint32_t s_px = (uint32_t)__builtin_amdgcn_readlane((int)pix, victim);
+                const uint32_t s_iso = (uint32_t)__builtin_amdgcn_readlane((int)iso, victim);
+                const uint32_t s_last = (uint32_t)__builtin_amdgcn_readlane((int)iso_last, victim);
+                const uint32_t mid = s_iso + ((s_last - s_iso) >> 1); /* the victim keeps [iso, mid] */
+#ifdef VR_DIAG
+                d_acc[9] += 1;
+#endif
+                if (lane == victim) iso_last = mid;
+                if (lane == thief) {
+                    L.dx = s_dx; L.dy = s_dy; L.dz = s_dz; L.rx = s_rx; L.ry = s_ry; L.rz = s_rz; L.posmask = s_pm;
+                    t0 = s_t0; cell0 = s_c0; pix = s_px;
+                    iso = mid + 1u; iso_last = s_last;
+                    vr_lane_restart(L, stack, v, t0, cell0);
+                    track.upper = 255u;
+                    moves = 0; esc = 0;
+                    alive = true;
+                    popping = false;
+                }
+            }
+        }
+#ifdef VR_DIAG
+        d_acc[4] += 1; d_acc[5] += __popcll(__ballot(alive));
+        if (exhausted) { d_acc[10] += 1; d_acc[11] += __popcll(__ballot(alive)); }
+#endif
 
         if (alive) {
             uint32_t go = VR_GO_MORE;
@@ -648,6 +714,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 /* ---- the traversal stands for every iso value from `iso` to `e` ---- */
                 const uint32_t e = track.upper < iso_last ? track.upper : iso_last;
                 const uint32_t k0 = iso - iso_begin, k1 = e + 1u - iso_begin;
+#ifdef VR_DIAG
+                d_lane_traces += 1; d_lane_emit += hit ? k1 - k0 : 0u;
+#endif
                 atomicAdd(&s_checks[k0], (unsigned long long)L.checked);
                 atomicAdd(&s_checks[k1], 0ull - (unsigned long long)L.checked);
                 uint32_t *c = s_cnt + (hit ? 0u : n_k);
@@ -684,6 +753,24 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
         }
     }
 
+#ifdef VR_DIAG
+    {
+        const unsigned long long d_end = __builtin_amdgcn_s_memtime();
+        d_acc[6] = wave_sum(d_lane_traces); d_acc[8] = wave_sum(d_lane_emit);
+        {
+            const uint32_t gwv = blockIdx.x * (kTraceThreads / 64u) + (threadIdx.x >> 6);
+            const unsigned long long d_rend = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0 && gwv < 8192u) { g_wave_span[3 * gwv] = d_rbegin; g_wave_span[3 * gwv + 1] = d_rexh ? d_rexh : d_rend; g_wave_span[3 * gwv + 2] = d_rend; }
+        }
+        d_acc[0] = (d_exh ? d_exh : d_end) - d_begin;
+        d_acc[1] = d_end - d_begin;
+        d_acc[3] = 1;
+        if (lane == 0) {
+            for (int i = 0; i < 20; i++) atomicAdd(&g_diag[i], d_acc[i]);
+            atomicMax(&g_diag[19], d_end - d_begin);
+        }
+    }
+#endif
     /* ---- per-iso counters: prefix sums of the difference arrays, then one atomic per iso value and counter ---- */
     __syncthreads();
     if (threadIdx.x < kSweepCounters) {
@@ -833,6 +920,31 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z);
+        if (sweep) {
+            static unsigned long long span[3 * 8192];
+            (void)hipMemcpyFromSymbol(span, HIP_SYMBOL(g_wave_span), sizeof span);
+            const uint32_t nw = (uint32_t)h[3] < 8192u ? (uint32_t)h[3] : 8192u;
+            unsigned long long t_min = ~0ull, t_max = 0;
+            for (uint32_t i = 0; i < nw; i++) { if (span[3 * i] < t_min) t_min = span[3 * i]; if (span[3 * i + 2] > t_max) t_max = span[3 * i + 2]; }
+            uint32_t hist_end[10] = { 0 }, hist_exh[10] = { 0 };
+            for (uint32_t i = 0; i < nw; i++) {
+                hist_end[(uint32_t)(9.999 * (double)(span[3 * i + 2] - t_min) / (double)(t_max - t_min))]++;
+                hist_exh[(uint32_t)(9.999 * (double)(span[3 * i + 1] - t_min) / (double)(t_max - t_min))]++;
+            }
+            fprintf(stderr, "[diag sweep] kernel span %llu x 10 ns; waves by end time (deciles of the span):", t_max - t_min);
+            for (int i = 0; i < 10; i++) fprintf(stderr, " %u", hist_end[i]);
+            fprintf(stderr, "\n[diag sweep] waves by the time they found the queue empty:");
+            for (int i = 0; i < 10; i++) fprintf(stderr, " %u", hist_exh[i]);
+            fprintf(stderr, "\n");
+            const double w = (double)h[3];
+            fprintf(stderr,
+                    "[diag sweep] waves %.0f  mean cycles/wave %.0f  slowest wave %.0f  mean cycles until the queue was empty %.0f (%.0f%%)\n"
+                    "[diag sweep] rounds/wave %.0f  alive lanes/round %.1f  traversals %.0f (%.1f per lane)  hit pixels written %.0f\n",
+                    w, h[1] / w, (double)h[19], h[0] / w, 100.0 * h[0] / (double)h[1], h[4] / w, h[5] / (double)h[4], (double)h[6],
+                    h[6] / (w * 64.0), (double)h[8]);
+            fprintf(stderr, "[diag sweep] after the queue was empty: rounds/wave %.0f, alive lanes/round %.1f, hand-overs/wave %.1f\n",
+                    h[10] / w, h[11] / (double)(h[10] ? h[10] : 1), h[9] / w);
+        } else {
         const double w = (double)h[16], it = (double)h[5];
         fprintf(stderr,
                 "[diag] waves %.0f  cycles/wave %.0f  rounds/wave %.0f  refill events/wave %.0f\n"
@@ -844,6 +956,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                 w, h[11] / w, it / w, h[17] / w, h[0] / it, h[1] / it, h[10] / it, h[2] / it, h[3] / it,
                 100.0 * h[14] / it, h[4] / it, h[6] / it, h[7] / (double)h[2], h[8] / it, h[9] / (double)h[4],
                 h[15] / it, h[15] / (double)h[6], h[13] / it, h[12] / it, h[12] / (double)h[8]);
+        }
     }
 #endif
     return hipSuccess;
