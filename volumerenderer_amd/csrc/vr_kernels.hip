@@ -898,10 +898,13 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     const int fn_id = (sweep ? 2 : 0) + (any_tap ? 1 : 0);
     const void *fn = sweep ? (any_tap ? (const void *)vr_k_sweep<true> : (const void *)vr_k_sweep<false>)
                            : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
-    static bool lds_set[4] = { false, false, false, false };
-    if (!lds_set[fn_id]) {
+    /* the attribute is a property of the function on the current device: set once per device and kernel */
+    static bool lds_set[64][4];
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !lds_set[dev][fn_id]) {
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u))) != hipSuccess) return e;
-        lds_set[fn_id] = true;
+        if (dev >= 0 && dev < 64) lds_set[dev][fn_id] = true;
     }
     const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
     const uint64_t frame_pixels = n_pix;
