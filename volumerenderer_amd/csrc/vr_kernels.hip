@@ -545,6 +545,12 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
 #ifndef VR_SWEEP_ITEMS_PER_LANE
 #define VR_SWEEP_ITEMS_PER_LANE 12
 #endif
+#ifndef VR_SWEEP_DESCEND_TRIPS
+#define VR_SWEEP_DESCEND_TRIPS 5
+#endif
+#ifndef VR_SWEEP_POP_TRIPS
+#define VR_SWEEP_POP_TRIPS 7
+#endif
 #ifndef VR_SWEEP_REFILL_MIN
 #define VR_SWEEP_REFILL_MIN 16
 #endif
@@ -560,6 +566,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
 /* once the queue is empty: hand-overs of half an iso range to an idle lane per wave and round, and the
  * shortest range (iso values behind the current one) worth splitting */
 constexpr uint32_t kSweepSteals = VR_SWEEP_STEALS, kSweepStealMin = VR_SWEEP_STEAL_MIN;
+constexpr uint32_t kSweepDescendTrips = VR_SWEEP_DESCEND_TRIPS, kSweepPopTrips = VR_SWEEP_POP_TRIPS; /* lanes of a wave are less alike here */
 constexpr uint32_t kSweepRefillMin = VR_SWEEP_REFILL_MIN; /* items last long here: refills are rare */
 constexpr uint32_t kSweepCounters = 5; /* hit, miss, moves, escape help, errors (u32 each); checks are u64 */
 
@@ -696,7 +703,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
         if (alive) {
             uint32_t go = VR_GO_MORE;
             /* ---- descend while the node's density range holds the iso value (bounded) ---- */
-            if (!popping) go = vr_lane_descend(L, iso, fetch, stack, kDescendTrips, track);
+            if (!popping) go = vr_lane_descend(L, iso, fetch, stack, kSweepDescendTrips, track);
             bool done = false, hit = false;
             uint32_t err = 0;
             if (go == VR_GO_HIT) {
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 if (in_root) popping = true; else done = true; /* left the volume: a miss (src/raytrace.zig:66-68) */
             }
             /* ---- pop to the lowest ancestor that holds the new point (bounded) ---- */
-            if (popping && !done) popping = !vr_lane_pop(L, stack, kPopTrips);
+            if (popping && !done) popping = !vr_lane_pop(L, stack, kSweepPopTrips);
 
             if (done) {
                 /* ---- the traversal stands for every iso value from `iso` to `e` ---- */
