@@ -35,10 +35,19 @@ pub const RenderStats = extern struct {
     errors: u64,
 };
 
+/// PartitionBuildData (src/SlimKDT.zig:215-219)
+pub const BuildStats = extern struct { non_center_partition_count: u64, layer_count: u64, number_of_nodes: u64 };
+
 pub extern fn vr_strerror(code: c_int) [*:0]const u8;
 pub extern fn vr_ctx_create(device: c_int, out: *?*Ctx) c_int;
 pub extern fn vr_ctx_destroy(ctx: ?*Ctx) void;
 pub extern fn vr_upload_kdt(ctx: ?*Ctx, nodes: [*]const u32, n_slots: u64, root_dim: *const [3]u8) c_int;
+pub extern fn vr_upload_volume(ctx: ?*Ctx, vox: [*]const u8, rx: u32, ry: u32, rz: u32) c_int;
+pub extern fn vr_build_kdt(ctx: ?*Ctx, heuristic: c_int, stats_out: ?*BuildStats) c_int;
+pub extern fn vr_download_kdt(ctx: ?*Ctx, nodes_out: ?[*]u32, capacity: u64, n_slots_out: *u64, root_dim_out: *[3]u8) c_int;
+pub extern fn vr_save_kdt(path: [*:0]const u8, nodes: [*]const u32, n_slots: u64, root_dim: *const [3]u8) c_int;
+pub extern fn vr_load_kdt(path: [*:0]const u8, nodes_out: *?[*]u32, n_slots_out: *u64, root_dim_out: *[3]u8) c_int;
+pub extern fn vr_free(p: ?*anyopaque) void;
 pub extern fn vr_render(ctx: ?*Ctx, view: *const View, isoval: u8, rgb24_out: [*]u8, stats_out: ?*RenderStats, taps: ?*const anyopaque) c_int;
 pub extern fn vr_render_sweep(ctx: ?*Ctx, view: *const View, iso_begin: u32, iso_count: u32, rgb24_out: [*]u8, stats_out: ?[*]RenderStats, taps: ?*const anyopaque) c_int;
 
