@@ -367,6 +367,19 @@ def test_sweep_kernel_equals_per_iso_kernel_at_full_size(oracle, skull_vox, skul
     assert bool(torch.equal(res[0][0], res[1][0]))
 
 
+def test_sweep_kernel_with_no_ray_entering_the_volume(oracle, c60_vox, c60_renderer):
+    """A camera that looks away from the volume: every frame black, every ray OOB in every iso value, nothing hangs."""
+    pos = np.array([-30.0, -300.0, -30.0], np.float32)
+    forw = np.array([0.0, -1.0, 0.0], np.float32)
+    up = np.array([0.0, 0.0, 1.0], np.float32)
+    for variant in (capi.KERNEL_SWEEP, capi.KERNEL_PIPELINE):
+        c60_renderer.set_kernel(variant)
+        out = c60_renderer.renderSweep(pos, forw, up, 70, 50, 2.0, 0, 256)
+        c60_renderer.set_kernel(capi.KERNEL_DEFAULT)
+        assert not out["rgb"].any()
+        assert all(s["oob_count"] == 70 * 50 and s["nodes_checked"] == 0 and s["hit_count"] == 0 for s in out["stats"])
+
+
 def test_vr_bench_driver_reproduces_reference_renders(tmp_path, golden_gray):
     """The C++ driver with the shape of the reference's main: writes renders/out_iso{d}.png and prints the
     comparison table; its files decode to the reference's own images."""
