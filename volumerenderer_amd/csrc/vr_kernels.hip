@@ -225,8 +225,12 @@ __device__ __forceinline__ bool tile_ray(const VrViewK &v, uint32_t tile, uint32
                                          VrRay &ray, uint32_t &pix)
 {
     const uint32_t st = tile / (kSuper * kSuper), in = tile % (kSuper * kSuper), sx = super_tiles_x(v.width);
+    /* rows of super-tiles from the middle of the image outwards (middle, one above, one below, ...): what is
+     * still in the queue at the end of a launch is the border of the image, where rays are short */
+    const uint32_t row_i = st / sx, mid = super_tiles_y(n_rows) / 2u;
+    const uint32_t row = (row_i & 1u) ? mid - (row_i + 1u) / 2u : mid + row_i / 2u;
     const uint32_t xi = ((st % sx) * kSuper + in % kSuper) * kTileW + (lane & 7u);
-    const uint32_t yr = ((st / sx) * kSuper + in / kSuper) * kTileH + (lane >> 3);
+    const uint32_t yr = (row * kSuper + in / kSuper) * kTileH + (lane >> 3);
     pix = yr * v.width + xi;
     if (xi >= v.width || yr >= n_rows) return false;
     ray = vr_make_ray(v, xi, yr + row_begin);
