@@ -145,6 +145,14 @@ def test_heuristic_trees(oracle, c60_vox, heuristic):
             got = _gpu(r, pos, forw, up, 256, 256, 2.0, iso)
             assert_same_render(got, ref, "%s iso %d" % (heuristic, iso))
             _check_stats(got, ref)
+        # and the sweep kernel on the same (unbalanced) tree: a block of iso values against one oracle render each
+        out = r.renderSweep(pos, forw, up, 72, 56, 2.0, 90, 24, taps=True)
+        for j in range(24):
+            ref = oracle.render(k.nodes, k.root_dim, pos, forw, up, 72, 56, 2.0, 90 + j)
+            got = {"rgb": out["rgb"][j], "cell_flag": out["cell_flag"][j], "t": out["t"][j], "checked": out["checked"][j],
+                   "node": out["node"][j], "stats": out["stats"][j]}
+            assert_same_render(got, ref, "%s sweep iso %d" % (heuristic, 90 + j))
+            _check_stats(got, ref)
 
 
 @pytest.mark.parametrize("size", [(1, 1), (7, 5), (37, 53), (130, 17), (256, 1)])
