@@ -7,13 +7,14 @@ reference camera (src/main.zig:31-43), i.e. 256 x 1 048 576 primary rays per ste
 rays count, including the ones that miss the volume -- the reference's ms/frame includes them too.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--gather]
-                    [--kernel V] [--width PX] [--volume skull|c60|standin256] [--no-cpu-baseline]
+                    [--shard iso|rows] [--kernel V] [--width PX] [--volume skull|c60|standin256] [--no-cpu-baseline]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`
 (one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE from the environment).  The path shards with no
 data-path collective: every rank holds a replica of the node array.
   weak   (default) each rank renders the whole 256-iso sweep; the job is N sweeps
-  strong the 256 iso values of ONE sweep are split into N contiguous blocks (north-star sharding)
+  strong the 256 iso values of ONE sweep are split into N contiguous blocks (north-star sharding), or,
+         with --shard rows, the rows of every frame
 --gather adds the one real exchange step: framebuffers are gathered to rank 0 over RCCL inside the
 timed region.
 
@@ -130,6 +131,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--shard", choices=["iso", "rows"], default="iso",
+                    help="with --scaling strong: split the iso values (default) or the image rows over the ranks")
     ap.add_argument("--gather", action="store_true")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--width", type=int, default=1024)
@@ -174,19 +177,26 @@ def main():
     r.upload_volume(data)
     build = r.build_kdt("AlwaysCenter")  # centre-split tree built on the GPU from the uploaded volume
     r.set_kernel(args.kernel)
-    if args.scaling == "strong":
+    row_begin, row_end = 0, H
+    if args.scaling == "strong" and args.shard == "rows":
+        if args.gather:
+            raise SystemExit("--gather goes with iso sharding")
+        iso_begin, iso_count = 0, 256
+        counts = [256] * world
+        row_begin, row_end = sharding.row_shard(rank, world, H)
+    elif args.scaling == "strong":
         iso_begin, iso_count = sharding.iso_shard(rank, world, 0, 256)
         counts = [sharding.iso_shard(k, world, 0, 256)[1] for k in range(world)]
     else:
         iso_begin, iso_count = 0, 256
         counts = [256] * world
     view = vr.raytrace._view(pos, forw, up, W, H, 2.0)
-    d_rgb = torch.empty((iso_count, H, W, 3), dtype=torch.uint8, device="cuda")
+    d_rgb = torch.empty((iso_count, row_end - row_begin, W, 3), dtype=torch.uint8, device="cuda")
     d_stats = torch.zeros((iso_count, 7), dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        capi.check(L.vr_render_device(r.handle, C.byref(view), iso_begin, iso_count, 0, H, d_rgb.data_ptr(),
+        capi.check(L.vr_render_device(r.handle, C.byref(view), iso_begin, iso_count, row_begin, row_end, d_rgb.data_ptr(),
                                       d_stats.data_ptr(), None, C.c_void_p(stream)), "vr_render_device")
         if args.gather and world > 1:
             sharding.gather_frames(d_rgb, counts, dst=0)
@@ -218,7 +228,7 @@ def main():
     stats = d_stats.cpu().numpy()
     nodes_checked = int(stats[:, 0].sum())
     errors = int(stats[:, 6].sum())
-    rays_per_step_rank = iso_count * W * H
+    rays_per_step_rank = iso_count * W * (row_end - row_begin)
     rays_total = torch.tensor([rays_per_step_rank], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)
@@ -254,8 +264,9 @@ def main():
                        "tree": "SlimKDT AlwaysCenter built on the GPU, %d nodes, depth %d" % (
                            build.number_of_nodes, build.layer_count),
                        "rays_per_step": int(rays_per_step),
-                       "sharding": "none" if world == 1 else ("iso-blocks" if args.scaling == "strong" else
-                                                              "one sweep per rank"),
+                       "sharding": "none" if world == 1 else (
+                           ("row-blocks" if args.shard == "rows" else "iso-blocks") if args.scaling == "strong" else
+                           "one sweep per rank"),
                        "gather": bool(args.gather and world > 1),
                        "kernel": capi.lib().vr_kernel_name(args.kernel).decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
