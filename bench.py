@@ -274,6 +274,10 @@ def main():
                          "kernel": {0: "vr_k_sweep", 4: "vr_k_trace", 5: "vr_k_sweep"}.get(args.kernel, "vr_k_render"), "kernel_ms": kernel_ms, "launches_timed": int(launches.value),
                          "algorithmic_bytes_per_launch": alg_bytes, "nodes_checked_per_launch": nodes_checked,
                          "measured_copy_GBps": copy_ceiling_gbps(torch),
+                         "note": ("algorithmic bytes = the reference's node reads (4 B x nodes_checked) + 3 B per pixel; the "
+                                  "kernels read far fewer nodes (resume traversal; the sweep kernel also shares traversals "
+                                  "between iso values), so frac prices the reference's work and can exceed 1 -- HBM itself "
+                                  "moves `traffic` bytes per launch"),
                          "counters": profile_counters() if (args.volume == "skull" and W == 1024) else None},
             "errors": errors,
         }
