@@ -6,7 +6,7 @@
 //!   raytrace.renderImage(src, forw, up, img, viewport_width, kdt, isoval, dbp, inner_dbp)
 //!       !struct { nodes_checked: u64 }                         (src/raytrace.zig:11-21)
 //!
-//! so that `main.zig` only has to swap its import (see INTEGRATION.md).  Vec3(f32) is a packed
+//! so that `main.zig` only has to swap its import.  Vec3(f32) is a packed
 //! struct and *zigimg.Image a Zig type: neither crosses the boundary, plain floats and pointers do.
 const std = @import("std");
 const geo = @import("geo.zig");
