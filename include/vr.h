@@ -150,6 +150,12 @@ void vr_main_camera(const uint32_t res[3], const float pos[3], float forw_out[3]
 
 void vr_free(void *p);
 
+/* Page-locked host memory for the outputs of vr_render / vr_render_sweep (the reference's image buffer is
+ * ordinary heap memory, src/main.zig:112; frames copied into pageable memory cross PCIe several times
+ * slower).  No counterpart in the reference.  Needs a GPU; release with vr_free_host. */
+int vr_alloc_host(size_t bytes, void **out);
+void vr_free_host(void *p);
+
 /* Output side of the reference driver (src/main.zig:116,137 writes renders/out_iso{d}.png through
  * zigimg): an 8-bit RGB PNG (stored deflate blocks, readable by any PNG decoder) or a binary PPM of
  * a finished width*height*3 frame. */

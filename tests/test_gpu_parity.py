@@ -388,6 +388,15 @@ def test_sweep_kernel_with_no_ray_entering_the_volume(oracle, c60_vox, c60_rende
         assert all(s["oob_count"] == 70 * 50 and s["nodes_checked"] == 0 and s["hit_count"] == 0 for s in out["stats"])
 
 
+def test_page_locked_output_buffer(oracle, c60_vox, c60_tree, c60_renderer):
+    """vr_alloc_host: frames delivered into page-locked memory equal frames delivered into ordinary memory."""
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    buf = c60_renderer.pinned_frames(6, 40, 64)
+    a = c60_renderer.renderSweep(pos, forw, up, 64, 40, 2.0, 97, 6, out=buf)
+    b = c60_renderer.renderSweep(pos, forw, up, 64, 40, 2.0, 97, 6)
+    assert a["rgb"] is buf and (buf == b["rgb"]).all() and buf.any()
+
+
 def test_vr_bench_driver_reproduces_reference_renders(tmp_path, golden_gray):
     """The C++ driver with the shape of the reference's main: writes renders/out_iso{d}.png and prints the
     comparison table; its files decode to the reference's own images."""

@@ -35,7 +35,7 @@ HEURISTICS = {
 
 # every symbol include/vr.h declares; tests check that the library exports each of them
 EXPORTS = [
-    "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
+    "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_alloc_host", "vr_free_host", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
     "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_render",
     "vr_render_sweep", "vr_render_device", "vr_sync", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
@@ -101,6 +101,9 @@ def lib():
     L.vr_write_ppm_rgb24.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
     L.vr_free.argtypes = [vp]
     L.vr_free.restype = None
+    L.vr_alloc_host.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.vr_free_host.argtypes = [vp]
+    L.vr_free_host.restype = None
     L.vr_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.vr_ctx_destroy.argtypes = [vp]
     L.vr_ctx_destroy.restype = None

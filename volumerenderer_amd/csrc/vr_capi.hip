@@ -121,6 +121,21 @@ int check_view(const vr_view *view)
 
 extern "C" {
 
+int vr_alloc_host(size_t bytes, void **out)
+{
+    if (!out || !bytes) return VR_EARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VR_ENODEVICE;
+    VR_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return VR_OK;
+}
+
+void vr_free_host(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int vr_ctx_create(int device, vr_ctx **out)
 {
     if (!out) return VR_EARG;

@@ -45,11 +45,15 @@ class Renderer:
         self._ctx = C.c_void_p()
         capi.check(self._L.vr_ctx_create(int(device), C.byref(self._ctx)), "vr_ctx_create")
         self.kdt = None
+        self._pinned = []
 
     def close(self):
         if self._ctx:
             self._L.vr_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
+        for _, p in getattr(self, "_pinned", []):
+            self._L.vr_free_host(p)
+        self._pinned = []
 
     def __enter__(self):
         return self
@@ -93,10 +97,23 @@ class Renderer:
         capi.check(self._L.vr_download_kdt(self._ctx, nodes.ctypes.data, n.value, C.byref(n), rd), "vr_download_kdt")
         return nodes, np.array(list(rd), dtype=np.uint8)
 
-    def renderSweep(self, src, forw, up, width, height, viewport_width, iso_begin, iso_count, taps=False):
-        """iso loop of src/main.zig:111-138.  Returns dict(rgb[iso,h,w,3], stats[list], + taps)."""
+    def pinned_frames(self, iso_count, height, width):
+        """uint8[iso_count, height, width, 3] in page-locked host memory (vr_alloc_host); the array keeps the
+        allocation alive and releases it when it is collected."""
+        n = int(iso_count) * int(height) * int(width) * 3
+        p = C.c_void_p()
+        capi.check(self._L.vr_alloc_host(n, C.byref(p)), "vr_alloc_host")
+        buf = (C.c_uint8 * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.uint8).reshape(iso_count, height, width, 3)
+        self._pinned.append((arr, p))
+        return arr
+
+    def renderSweep(self, src, forw, up, width, height, viewport_width, iso_begin, iso_count, taps=False, out=None):
+        """iso loop of src/main.zig:111-138.  Returns dict(rgb[iso,h,w,3], stats[list], + taps).  `out`: frames
+        buffer to fill (e.g. from pinned_frames) instead of a fresh pageable array."""
         v = _view(src, forw, up, width, height, viewport_width)
-        rgb = np.zeros((iso_count, height, width, 3), dtype=np.uint8)
+        rgb = out if out is not None else np.zeros((iso_count, height, width, 3), dtype=np.uint8)
+        assert rgb.shape == (iso_count, height, width, 3) and rgb.dtype == np.uint8 and rgb.flags.c_contiguous
         stats = (capi.RenderStats * iso_count)()
         out = {"rgb": rgb}
         tp = None
