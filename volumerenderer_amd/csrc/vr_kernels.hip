@@ -2,7 +2,7 @@
  * vr_kernels.hip -- gfx950 kernels of the isosurface ray caster (renderImage / traceRay,
  * src/raytrace.zig:11-106, 117-255).  The per-ray arithmetic lives in vr_trace_core.h.
  *
- * The path is VALU/latency-bound pointer chasing over 4-byte nodes with no matrix work (no MFMA).
+ * The path is latency-bound pointer chasing over 4-byte nodes with no matrix work (no MFMA).
  * Two families of kernels:
  *
  *  per-pixel   one thread per pixel and iso value, 8x8-pixel tiles per wave64.  The literal
@@ -20,6 +20,10 @@
  *       and not the VALU.  Waves pull rays of one iso value at a time from that iso's queue and refill
  *       idle lanes as their rays finish.  Traversal resumes from the lowest valid ancestor after each
  *       MOVE (path stack in LDS) instead of restarting at the root.  Only hit pixels are stored.
+ *    4. for more than one iso value, the sweep kernel: the same machinery, but a lane owns a ray and a
+ *       block of iso values, and one traversal serves every iso value that cannot change the outcome
+ *       of any density-range test on its way (same pixels and counters as one traversal per iso
+ *       value, a quarter of the node reads on the reference's CT volume).
  */
 #include <cstdio>
 #include <cstdlib>
