@@ -397,6 +397,28 @@ def test_page_locked_output_buffer(oracle, c60_vox, c60_tree, c60_renderer):
     assert a["rgb"] is buf and (buf == b["rgb"]).all() and buf.any()
 
 
+def test_sweep_kernel_on_random_small_volumes(oracle):
+    """Noise, smooth and sparse volumes of odd shapes from odd camera positions, all 256 iso values through the
+    sweep kernel (noise gives almost every iso value its own walk, sparse volumes give long shared ones)."""
+    rng = np.random.default_rng(23)
+    for shape, kind, cam in [((5, 9, 3), "noise", (-30.0, -300.0, -30.0)), ((20, 33, 17), "noise", (350.0, 20.0, 10.0)),
+                             ((33, 20, 41), "smooth", (8.0, 8.0, -320.0)), ((40, 40, 40), "sparse", (-200.0, 260.0, 190.0)),
+                             ((2, 2, 2), "noise", (-30.0, -300.0, -30.0))]:
+        vox = random_volume(rng, shape, kind)
+        k = vr.SlimKDT.newHeursiticPartition(vr.Data(vox), "AlwaysCenter")
+        pos, forw, up = oracle.main_camera(shape, cam)
+        with vr.Renderer(0) as r:
+            r.upload_kdt(k)
+            r.set_kernel(capi.KERNEL_SWEEP)
+            out = r.renderSweep(pos, forw, up, 48, 40, 0.5, 0, 256, taps=True)
+        for j in range(0, 256, 3):
+            ref = oracle.render(k.nodes, k.root_dim, pos, forw, up, 48, 40, 0.5, j)
+            got = {"rgb": out["rgb"][j], "cell_flag": out["cell_flag"][j], "t": out["t"][j], "checked": out["checked"][j],
+                   "node": out["node"][j], "stats": out["stats"][j]}
+            assert_same_render(got, ref, "%s %s iso %d" % (shape, kind, j))
+            _check_stats(got, ref)
+
+
 def test_vr_bench_driver_reproduces_reference_renders(tmp_path, golden_gray):
     """The C++ driver with the shape of the reference's main: writes renders/out_iso{d}.png and prints the
     comparison table; its files decode to the reference's own images."""
