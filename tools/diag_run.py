@@ -1,11 +1,12 @@
 """Runs one sweep of the pipeline kernel on a chosen volume (for the diagnostic build's stderr report).
-usage: python tools/diag_run.py {skull|c60|cube16|cube32|noise64} [width]"""
+usage: python tools/diag_run.py {skull|c60|cube16|cube32|noise64} [width] [kernel id, default 0]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import volumerenderer_amd as vr
 from volumerenderer_amd import capi
 which = sys.argv[1]; W = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+kernel = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rng = np.random.default_rng(3)
 if which == "skull": data = vr.Data.loadUCD(os.path.join(root, "tests/data/Skull.vol.gz"))
@@ -17,7 +18,7 @@ else: data = vr.Data(rng.integers(0, 256, (64, 64, 64), dtype=np.uint8))
 kdt = vr.SlimKDT.newHeursiticPartition(data, "AlwaysCenter")
 pos, forw, up = vr.main_camera(data.resulution)
 vp = 2.0 * max(data.resulution) / 256.0  # keep the volume's share of the image similar to Skull's
-L = capi.lib(); r = vr.Renderer(0); r.upload_kdt(kdt)
+L = capi.lib(); r = vr.Renderer(0); r.upload_kdt(kdt); r.set_kernel(kernel)
 view = vr.raytrace._view(pos, forw, up, W, W, vp)
 d_rgb = torch.empty((256, W, W, 3), dtype=torch.uint8, device="cuda"); d_stats = torch.zeros((256, 7), dtype=torch.int64, device="cuda")
 for it in range(2):
