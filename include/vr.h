@@ -221,7 +221,7 @@ int vr_sync(vr_ctx *ctx);
 int vr_set_timing(vr_ctx *ctx, int enabled);
 int vr_timing_read(vr_ctx *ctx, double *total_ms_out, uint32_t *launches_out);
 
-/* Traversal kernel selection: 0 = default (fastest verified: for more than one iso value the sweep
+/* Traversal kernel selection: 0 = default (fastest verified: from 8 iso values on the sweep
  * kernel, which traces a ray once per interval of iso values that cannot change the outcome of any
  * density-range test and gives every iso value of the interval that result), other values name the
  * variants listed by vr_kernel_name.  All variants produce identical results. */

@@ -22,9 +22,9 @@ enum {
     VR_KERNEL_RESTART_LDS = 2,    /* root-restart loop, top tree levels staged in LDS                  */
     VR_KERNEL_RESUME = 3,         /* per-pixel threads, path stack in LDS, resume after a MOVE         */
     VR_KERNEL_PIPELINE = 4,       /* compacted ray list + persistent waves with lane refill, one       */
-                                  /* traversal per ray and iso value (default for a single iso value)  */
+                                  /* traversal per ray and iso value (default for fewer than 8 iso values)  */
     VR_KERNEL_SWEEP = 5,          /* the same machinery with traversals shared between iso values      */
-                                  /* (default for more than one iso value)                             */
+                                  /* (default from 8 iso values on)                                   */
     VR_KERNEL_COUNT = 6
 };
 
