@@ -427,11 +427,13 @@ def test_vr_bench_driver_reproduces_reference_renders(tmp_path, golden_gray):
     PIL = pytest.importorskip("PIL.Image")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "volumerenderer_amd", "vr_bench")
-    out = subprocess.run([exe, "--volume", os.path.join(root, "tests", "data", "C60.vol"), "--size", "512", "--iso",
-                          "97:103", "--heuristics", "center", "--out", str(tmp_path)], capture_output=True, text=True,
-                         timeout=120)
-    assert out.returncode == 0, out.stderr
-    assert "(ms/frame)" in out.stdout and "nodes: 500093" in out.stdout and "layers: 18" in out.stdout
-    for iso in range(97, 103):
-        img = np.asarray(PIL.open(tmp_path / ("out_iso%d.png" % iso)).convert("RGB"))
-        assert (img[..., 0] == golden_gray[iso]).all() and (img[..., 1] == img[..., 0]).all()
+    for extra, lo, hi in [([], 97, 103), (["--sweep"], 90, 110)]:
+        out = subprocess.run([exe, "--volume", os.path.join(root, "tests", "data", "C60.vol"), "--size", "512", "--iso",
+                              "%d:%d" % (lo, hi), "--heuristics", "center", "--out", str(tmp_path)] + extra,
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert "(ms/frame)" in out.stdout and "nodes: 500093" in out.stdout and "layers: 18" in out.stdout
+        for iso in range(lo, hi):
+            img = np.asarray(PIL.open(tmp_path / ("out_iso%d.png" % iso)).convert("RGB"))
+            assert (img[..., 0] == golden_gray[iso]).all() and (img[..., 1] == img[..., 0]).all()
+            os.remove(tmp_path / ("out_iso%d.png" % iso))

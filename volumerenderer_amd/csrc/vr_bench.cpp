@@ -6,7 +6,7 @@
  * Host side of the library above its C ABI; the rendering itself runs on the GPU.
  *
  *   vr_bench [--volume C60.vol] [--size 512] [--iso 0:256] [--heuristics main|center|all]
- *            [--out DIR | --no-images] [--device 0] [--viewport 2.0] [--camera x,y,z]
+ *            [--out DIR | --no-images] [--sweep] [--device 0] [--viewport 2.0] [--camera x,y,z]
  */
 #include <chrono>
 #include <cstdio>
@@ -49,6 +49,7 @@ int main(int argc, char **argv)
     uint32_t size = 512, iso_begin = 0, iso_end = 256;
     int device = 0;
     bool images = true;
+    bool sweep = false; /* the whole iso loop in one vr_render_sweep call (frames into page-locked memory) */
     float viewport = 2.0f, cam[3] = { -30.0f, -300.0f, -30.0f }; /* src/main.zig:37,126 */
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -59,6 +60,7 @@ int main(int argc, char **argv)
         else if (a == "--heuristics") heur = next();
         else if (a == "--out") out_dir = next();
         else if (a == "--no-images") images = false;
+        else if (a == "--sweep") sweep = true;
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--viewport") viewport = (float)std::atof(next());
         else if (a == "--camera") { if (std::sscanf(next(), "%f,%f,%f", &cam[0], &cam[1], &cam[2]) != 3) { std::fprintf(stderr, "--camera x,y,z\n"); return 2; } }
@@ -108,6 +110,27 @@ int main(int argc, char **argv)
                     (unsigned long long)bs.layer_count);
         double tot_ms = 0.0;
         uint64_t node_checks = 0;
+        if (sweep) {
+            /* src/main.zig:111-138 as one call: a ray is traced once per interval of iso values that cannot change
+             * the outcome of a range test on its way; every frame and counter equals the per-iso call's */
+            const size_t frame = (size_t)size * size * 3u;
+            void *frames = nullptr;
+            CHECK(vr_alloc_host(frame * n_iso, &frames));
+            std::vector<vr_render_stats> st(n_iso);
+            const auto t0 = std::chrono::steady_clock::now();
+            CHECK(vr_render_sweep(ctx, &view, iso_begin, n_iso, (uint8_t *)frames, st.data(), nullptr));
+            const auto t1 = std::chrono::steady_clock::now();
+            tot_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            for (uint32_t k = 0; k < n_iso; k++) {
+                node_checks += st[k].nodes_checked;
+                if (images) {
+                    char name[512];
+                    std::snprintf(name, sizeof name, "%s/out_iso%u.png", out_dir.c_str(), iso_begin + k);
+                    CHECK(vr_write_png_rgb24(name, size, size, (const uint8_t *)frames + frame * k));
+                }
+            }
+            vr_free_host(frames);
+        } else
         for (uint32_t iso = iso_begin; iso < iso_end; iso++) {
             vr_render_stats st;
             const auto t0 = std::chrono::steady_clock::now();
