@@ -96,6 +96,7 @@ typedef struct vr_view {
  * transiently. */
 typedef struct vr_taps {
     uint32_t *cell_flag; /* x | y<<8 | z<<16 | VR_FLAG_*<<24 ; cell is 0 unless the ray hit   */
+                         /* (wide trees: x | y<<10 | z<<20 | VR_FLAG_*<<30)                    */
     float *t;            /* RayRes.t ; 0 for OOB rays                                          */
     uint32_t *checked;   /* RayRes.checked_nodes                                               */
     uint32_t *node;      /* heap index of the hit leaf ; 0 unless the ray hit                  */
@@ -170,7 +171,8 @@ int vr_ctx_create(int device, vr_ctx **out);
 void vr_ctx_destroy(vr_ctx *ctx);
 
 /* Uploads Data.data verbatim (src/Data.zig:4-6, layout :90-92).  Needed by vr_build_kdt only:
- * the render path never reads voxels (src/raytrace.zig:117-255 reads kdt.nodes alone). */
+ * the render path never reads voxels (src/raytrace.zig:117-255 reads kdt.nodes alone).
+ * 2..256 voxels per axis is the reference's range; up to 1024 per axis is accepted for wide trees (below). */
 int vr_upload_volume(vr_ctx *ctx, const uint8_t *vox, uint32_t rx, uint32_t ry, uint32_t rz);
 
 /* Uploads SlimKDT.nodes verbatim (src/SlimKDT.zig:17) with root_dim (:15).  Bits 26..31 of each
@@ -184,9 +186,28 @@ int vr_upload_kdt(vr_ctx *ctx, const uint32_t *nodes, uint64_t n_slots, const ui
 int vr_build_kdt(vr_ctx *ctx, int heuristic, vr_build_stats *stats_out);
 
 /* Copies the device-resident tree back (for parity checks and caching). nodes_out may be NULL to
- * query n_slots only. */
+ * query n_slots only.  VR_ESTATE when the context holds a wide tree (vr_download_kdt_wide). */
 int vr_download_kdt(vr_ctx *ctx, uint32_t *nodes_out, uint64_t cap_slots, uint64_t *n_slots_out,
                     uint8_t root_dim_out[3]);
+
+/* ---- volumes beyond the reference's coordinate range ------------------------------------ */
+
+/* The reference keeps coordinates in u8 (SPACESIZE, src/typedef.zig:1) and the partition in one byte of
+ * SlimNode (src/SlimKDT.zig:9-13): it ends at 256 voxels per axis.  These entry points have no
+ * counterpart in it.  They run the same algorithm (same f32 operations in the same order, same heap
+ * layout, src/SlimKDT.zig:24-30) on up to 1024 voxels per axis with a wider node word:
+ *     wide node word   bits 0-7 min | 8-15 max | 16-27 partition | 28-29 axis
+ * A context holds a wide tree after vr_upload_kdt_wide, or after vr_build_kdt on a volume with an axis
+ * above 256 voxels (VR_H_ALWAYS_CENTER only, built on the GPU; 1024^3 voxels give 2^31 slots = 8 GiB).
+ * vr_render / vr_render_sweep / vr_render_device then work as for any other tree, with one difference:
+ * the cell/flag tap word is  x | y<<10 | z<<20 | VR_FLAG_*<<30.  A malformed wide tree cannot make the
+ * kernel read outside the array: such rays end as misses and are counted in vr_render_stats.errors. */
+int vr_upload_kdt_wide(vr_ctx *ctx, const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3]);
+
+/* Copies slots [first_slot, first_slot + n_slots) of the device-resident wide tree back (the whole
+ * array can be 8 GiB).  nodes_out may be NULL to query the array length and root_dim only. */
+int vr_download_kdt_wide(vr_ctx *ctx, uint32_t *nodes_out, uint64_t first_slot, uint64_t n_slots,
+                         uint64_t *n_slots_out, uint16_t root_dim_out[3]);
 
 /* ---- rendering -------------------------------------------------------------------------- */
 

@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvr_oracle.so")
+# the same C file built with u16 coordinates: volumes the reference cannot represent (up to 1024 per axis)
+_LIB_PATH_WIDE = os.path.join(_HERE, "libvr_oracle_wide.so")
 
 HEURISTICS = {
     "AlwaysCenter": 0,
@@ -44,22 +46,26 @@ class RenderStats(C.Structure):
 
 def build(force=False):
     """Compile the C restatement with the recipe in oracle/Makefile."""
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(
-            os.path.join(_HERE, "vr_oracle.c")):
+    src_time = os.path.getmtime(os.path.join(_HERE, "vr_oracle.c"))
+    if force or any(not os.path.exists(q) or os.path.getmtime(q) < src_time for q in (_LIB_PATH, _LIB_PATH_WIDE)):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+def _coord(wide):
+    return C.c_uint16 if wide else C.c_uint8
+
+
+def lib(wide=False):
+    if wide not in _libs:
+        path = _LIB_PATH_WIDE if wide else _LIB_PATH
+        if not os.path.exists(path):
             build()
-        L = C.CDLL(_LIB_PATH)
-        u8p, u32p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+        L = C.CDLL(path)
+        u8p, u32p, f32p = C.POINTER(_coord(wide)), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
         L.vro_build_kdt.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint64, C.POINTER(u32p),
                                     C.POINTER(C.c_uint64), u8p, C.POINTER(BuildStats)]
         L.vro_build_kdt.restype = C.c_int
@@ -71,10 +77,10 @@ def lib():
         L.vro_render_rows.restype = C.c_int
         L.vro_main_camera.argtypes = [u32p, f32p, f32p, f32p]
         L.vro_main_camera.restype = None
-        L.vro_load_ucd.argtypes = [C.c_char_p, C.POINTER(u8p), u32p]
+        L.vro_load_ucd.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), u32p]
         L.vro_load_ucd.restype = C.c_int
-        _lib = L
-    return _lib
+        _libs[wide] = L
+    return _libs[wide]
 
 
 def _f3(v):
@@ -106,23 +112,24 @@ def main_camera(res, pos=(-30.0, -300.0, -30.0)):
             np.array(list(u), dtype=np.float32))
 
 
-def build_kdt(vox, heuristic="AlwaysCenter", max_slots=0):
-    """SlimKDT.newHeursiticPartition: returns (nodes uint32[n_slots], root_dim uint8[3], BuildStats)."""
-    L = lib()
+def build_kdt(vox, heuristic="AlwaysCenter", max_slots=0, wide=False):
+    """SlimKDT.newHeursiticPartition: returns (nodes uint32[n_slots], root_dim uint8[3], BuildStats).
+    wide=True: u16 coordinates and the wide node word (root_dim comes back as uint16)."""
+    L = lib(wide)
     vox = np.ascontiguousarray(vox, dtype=np.uint8)
     assert vox.ndim == 3
     res = (C.c_uint32 * 3)(*vox.shape)
     h = HEURISTICS[heuristic] if isinstance(heuristic, str) else int(heuristic)
     p = C.POINTER(C.c_uint32)()
     n = C.c_uint64()
-    rd = (C.c_uint8 * 3)()
+    rd = (_coord(wide) * 3)()
     st = BuildStats()
     rc = L.vro_build_kdt(vox.ctypes.data, res, h, max_slots, C.byref(p), C.byref(n), rd, C.byref(st))
     if rc != 0:
         raise RuntimeError("vro_build_kdt failed: %d" % rc)
     nodes = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
     L.vro_free(p)
-    return nodes, np.array(list(rd), dtype=np.uint8), st
+    return nodes, np.array(list(rd), dtype=np.uint16 if wide else np.uint8), st
 
 
 def trim_nodes(nodes):
@@ -136,11 +143,12 @@ def trim_nodes(nodes):
 
 
 def render(nodes, root_dim, src, forw, up, width, height, viewport_width, iso, rows=None, taps=True,
-           out=None):
-    """raytrace.renderImage.  Returns dict(rgb, stats, cell_flag, t, checked, node)."""
-    L = lib()
+           out=None, wide=False):
+    """raytrace.renderImage.  Returns dict(rgb, stats, cell_flag, t, checked, node).
+    wide=True: nodes are wide node words; cell_flag packs x | y<<10 | z<<20 | flag<<30."""
+    L = lib(wide)
     nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
-    rd = (C.c_uint8 * 3)(*[int(x) for x in root_dim])
+    rd = (_coord(wide) * 3)(*[int(x) for x in root_dim])
     rgb = out if out is not None else np.zeros((height, width, 3), dtype=np.uint8)
     r0, r1 = (0, height) if rows is None else rows
     st = RenderStats()

@@ -32,10 +32,24 @@
 #define VRO_EARG (-4)
 #define VRO_ETOODEEP (-5)
 
+/* Coordinate type.  The reference's SPACESIZE is u8 (src/typedef.zig:1), so its volumes end at 256
+ * voxels per axis.  Built with -DVRO_WIDE the same code runs on u16 coordinates (up to 1024 voxels per
+ * axis) with a node word that holds a 12-bit partition:
+ *     bits 0-7 min | 8-15 max | 16-27 partition | 28-29 axis
+ * No reference artefact exists for such volumes; the wide build is pinned by agreeing with the u8 build
+ * (and through it with the reference's renders) on every volume both can represent. */
+#ifdef VRO_WIDE
+typedef uint16_t coord_t;
+#define VRO_MAX_RES 1024u
+#else
+typedef uint8_t coord_t;
+#define VRO_MAX_RES 256u
+#endif
+
 /* ---------------------------------------------------------------- geo.zig primitives ---- */
 
 typedef struct { float x, y, z; } vec3;                 /* src/geo.zig:55-60  Vec3(f32)       */
-typedef struct { uint8_t min, max; } range8;            /* src/geo.zig:155-159 Range(u8)      */
+typedef struct { coord_t min, max; } range8;            /* src/geo.zig:155-159 Range(u8)      */
 typedef struct { range8 r[3]; } box8;                   /* src/geo.zig:202-207 Volume(u8)     */
 
 static inline vec3 v_new(float x, float y, float z) { vec3 v = { x, y, z }; return v; }
@@ -85,19 +99,19 @@ static inline int box_contains_float(box8 b, vec3 p)
 /* src/geo.zig:315-317 (range len: src/geo.zig:192-194) */
 static inline uint32_t box_size(box8 b)
 {
-    return (uint32_t)(uint8_t)(b.r[0].max - b.r[0].min) * (uint32_t)(uint8_t)(b.r[1].max - b.r[1].min) *
-           (uint32_t)(uint8_t)(b.r[2].max - b.r[2].min);
+    return (uint32_t)(coord_t)(b.r[0].max - b.r[0].min) * (uint32_t)(coord_t)(b.r[1].max - b.r[1].min) *
+           (uint32_t)(coord_t)(b.r[2].max - b.r[2].min);
 }
 /* src/geo.zig:319-327 */
 static inline int box_largest_dim(box8 b)
 {
-    uint8_t lx = b.r[0].max - b.r[0].min, ly = b.r[1].max - b.r[1].min, lz = b.r[2].max - b.r[2].min;
+    coord_t lx = b.r[0].max - b.r[0].min, ly = b.r[1].max - b.r[1].min, lz = b.r[2].max - b.r[2].min;
     if (lx > ly && lx > lz) return 0;
     if (ly > lz) return 1;
     return 2;
 }
 /* src/geo.zig:256-275 : which = 0 -> the half below the split, 1 -> the half at/above it */
-static inline box8 box_split_global(box8 b, int axis, uint8_t split, int which)
+static inline box8 box_split_global(box8 b, int axis, coord_t split, int which)
 {
     if (which == 0) {
         if (split < b.r[axis].max) b.r[axis].max = split;
@@ -108,7 +122,7 @@ static inline box8 box_split_global(box8 b, int axis, uint8_t split, int which)
 }
 
 /* src/geo.zig:406-426  Plane.rayIntersect, written out literally (normal vector products kept) */
-static inline float plane_ray_intersect(int axis, uint8_t offset, vec3 o, vec3 d)
+static inline float plane_ray_intersect(int axis, coord_t offset, vec3 o, vec3 d)
 {
     vec3 normal = axis_base(axis);
     vec3 center = v_scale(normal, (float)offset);
@@ -119,7 +133,7 @@ static inline float plane_ray_intersect(int axis, uint8_t offset, vec3 o, vec3 d
     return -1.0f;
 }
 /* src/geo.zig:366-375  Volume.planes : index 2*axis -> min plane, 2*axis+1 -> max plane */
-static inline uint8_t box_plane_offset(box8 b, int plane_idx)
+static inline coord_t box_plane_offset(box8 b, int plane_idx)
 {
     return (plane_idx & 1) ? b.r[plane_idx >> 1].max : b.r[plane_idx >> 1].min;
 }
@@ -176,14 +190,19 @@ void vro_free(void *p) { free(p); }
 /* ------------------------------------------------------------------- SlimKDT.zig ------- */
 
 /* src/SlimKDT.zig:9-13 : packed struct, LSB first: min, max, partition, axis(2 bits) */
-static inline uint32_t node_pack(uint8_t mn, uint8_t mx, uint8_t part, int axis)
+#ifdef VRO_WIDE
+#define NODE_PART_BITS 12
+#else
+#define NODE_PART_BITS 8
+#endif
+static inline uint32_t node_pack(uint8_t mn, uint8_t mx, coord_t part, int axis)
 {
-    return (uint32_t)mn | ((uint32_t)mx << 8) | ((uint32_t)part << 16) | ((uint32_t)(axis & 3) << 24);
+    return (uint32_t)mn | ((uint32_t)mx << 8) | ((uint32_t)part << 16) | ((uint32_t)(axis & 3) << (16 + NODE_PART_BITS));
 }
 #define NODE_MIN(n) ((uint8_t)((n) & 0xff))
 #define NODE_MAX(n) ((uint8_t)(((n) >> 8) & 0xff))
-#define NODE_PART(n) ((uint8_t)(((n) >> 16) & 0xff))
-#define NODE_AXIS(n) ((int)(((n) >> 24) & 3))
+#define NODE_PART(n) ((coord_t)(((n) >> 16) & ((1u << NODE_PART_BITS) - 1u)))
+#define NODE_AXIS(n) ((int)(((n) >> (16 + NODE_PART_BITS)) & 3))
 
 typedef struct {
     uint64_t non_center_partition_count; /* src/SlimKDT.zig:215-219 */
@@ -237,7 +256,7 @@ static void box_corner_range(const build_ctx *c, box8 b, uint8_t *mn_out, uint8_
 }
 
 /* src/SlimKDT.zig:327-357 and the copies at :408-598 which differ only in the weight */
-static float span_heuristic(const build_ctx *c, uint8_t p, uint8_t mid, box8 space, int axis, float weight)
+static float span_heuristic(const build_ctx *c, coord_t p, coord_t mid, box8 space, int axis, float weight)
 {
     uint8_t lmin, lmax, rmin, rmax;
     box_corner_range(c, box_split_global(space, axis, p, 0), &lmin, &lmax);
@@ -250,9 +269,9 @@ static float span_heuristic(const build_ctx *c, uint8_t p, uint8_t mid, box8 spa
 }
 
 /* src/SlimKDT.zig:359-367 */
-static float always_center(uint8_t p, uint8_t mid) { return p == mid ? 0.0f : 1.0f; }
+static float always_center(coord_t p, coord_t mid) { return p == mid ? 0.0f : 1.0f; }
 
-static float heuristic_eval(const build_ctx *c, uint8_t p, uint8_t mid, box8 space, int axis, uint32_t layer)
+static float heuristic_eval(const build_ctx *c, coord_t p, coord_t mid, box8 space, int axis, uint32_t layer)
 {
     switch (c->heuristic) {
     case VRO_H_ALWAYS_CENTER: return always_center(p, mid);
@@ -297,13 +316,13 @@ static vro_build_stats build_inner(build_ctx *c, box8 space, uint64_t idx, uint3
     box_corner_range(c, space, &mn, &mx); /* :275-281 */
 
     /* :282-284 */
-    uint8_t mid = (uint8_t)(((uint32_t)space.r[axis].min + (uint32_t)space.r[axis].max) / 2);
-    uint8_t best = mid;
+    coord_t mid = (coord_t)(((uint32_t)space.r[axis].min + (uint32_t)space.r[axis].max) / 2);
+    coord_t best = mid;
     float best_h = INFINITY;
     /* :289-298 : candidates min+1 .. max-1, strict improvement keeps the first minimum */
     for (uint32_t cand = (uint32_t)space.r[axis].min + 1; cand < space.r[axis].max; cand++) {
-        float h = heuristic_eval(c, (uint8_t)cand, mid, space, axis, layer);
-        if (best_h > h) { best = (uint8_t)cand; best_h = h; }
+        float h = heuristic_eval(c, (coord_t)cand, mid, space, axis, layer);
+        if (best_h > h) { best = (coord_t)cand; best_h = h; }
     }
 
     c->nodes[idx] = node_pack(mn, mx, best, axis); /* :301-308 */
@@ -329,11 +348,11 @@ static vro_build_stats build_inner(build_ctx *c, box8 space, uint64_t idx, uint3
  * Returns a heap-indexed array of packed nodes (unreachable slots are zero; the reference leaves
  * them uninitialised).  *n_slots_out = array length.  Free with vro_free. */
 int vro_build_kdt(const uint8_t *vox, const uint32_t res[3], int heuristic, uint64_t max_slots,
-                  uint32_t **nodes_out, uint64_t *n_slots_out, uint8_t root_dim_out[3], vro_build_stats *stats_out)
+                  uint32_t **nodes_out, uint64_t *n_slots_out, coord_t root_dim_out[3], vro_build_stats *stats_out)
 {
     if (!vox || !res || heuristic < 0 || heuristic >= VRO_H_COUNT) return VRO_EARG;
     for (int a = 0; a < 3; a++)
-        if (res[a] < 2 || res[a] > 256) return VRO_EARG; /* SPACESIZE = u8: src/typedef.zig:1, src/SlimKDT.zig:129-133 */
+        if (res[a] < 2 || res[a] > VRO_MAX_RES) return VRO_EARG; /* SPACESIZE = u8: src/typedef.zig:1, src/SlimKDT.zig:129-133 */
     build_ctx c;
     c.vox = vox;
     c.res[0] = res[0]; c.res[1] = res[1]; c.res[2] = res[2];
@@ -345,12 +364,12 @@ int vro_build_kdt(const uint8_t *vox, const uint32_t res[3], int heuristic, uint
     c.heuristic = heuristic;
     c.err = 0;
     box8 root;
-    for (int a = 0; a < 3; a++) { root.r[a].min = 0; root.r[a].max = (uint8_t)(res[a] - 1); }
+    for (int a = 0; a < 3; a++) { root.r[a].min = 0; root.r[a].max = (coord_t)(res[a] - 1); }
     vro_build_stats st = build_inner(&c, root, 0, 0);
     if (c.err) { free(c.nodes); return c.err; }
     *nodes_out = c.nodes;
     *n_slots_out = c.cap;
-    for (int a = 0; a < 3; a++) root_dim_out[a] = (uint8_t)(res[a] - 1);
+    for (int a = 0; a < 3; a++) root_dim_out[a] = (coord_t)(res[a] - 1);
     if (stats_out) *stats_out = st;
     return VRO_OK;
 }
@@ -365,13 +384,13 @@ typedef struct {
     float enter_vol_t;
     uint64_t checked_nodes;
     /* extra parity taps the reference only holds transiently */
-    uint8_t cell[3];
+    coord_t cell[3];
     uint32_t node_idx;
     uint32_t moves;
 } ray_res;
 
 /* src/raytrace.zig:117-255 traceRay with the SpaceTracker of src/SlimKDT.zig:48-115 inlined */
-static ray_res trace_ray(vec3 o, vec3 d, const uint32_t *nodes, const uint8_t root_dim[3], uint8_t iso)
+static ray_res trace_ray(vec3 o, vec3 d, const uint32_t *nodes, const coord_t root_dim[3], uint8_t iso)
 {
     ray_res res;
     memset(&res, 0, sizeof res);
@@ -404,7 +423,7 @@ static ray_res trace_ray(vec3 o, vec3 d, const uint32_t *nodes, const uint8_t ro
     while (box_contains_float(space, ray_point(o, d, t))) { /* :161 */
         checked += 1;
         vec3 p = ray_point(o, d, t);
-        uint8_t cell[3] = { (uint8_t)p.x, (uint8_t)p.y, (uint8_t)p.z }; /* :163, src/geo.zig:74-81 */
+        coord_t cell[3] = { (coord_t)p.x, (coord_t)p.y, (coord_t)p.z }; /* :163, src/geo.zig:74-81 */
         uint32_t n = nodes[idx];
         range8 dr = { NODE_MIN(n), NODE_MAX(n) };
         if (range_contains_inclusive(dr, iso)) { /* :177 */
@@ -420,7 +439,7 @@ static ray_res trace_ray(vec3 o, vec3 d, const uint32_t *nodes, const uint8_t ro
             }
             /* SpaceTracker.zoom : src/SlimKDT.zig:90-103 */
             int axis = NODE_AXIS(n);
-            uint8_t part = NODE_PART(n);
+            coord_t part = NODE_PART(n);
             if (cell[axis] < part) {
                 space = box_split_global(space, axis, part, 0);
                 idx = 2 * idx + 1;
@@ -483,11 +502,12 @@ static inline uint8_t shade(float t)
 /* src/raytrace.zig:11-106 renderImage, rows [row_begin,row_end) of a width x height image.
  * rgb24 points at the FULL image (row-major, top row first, 3 B/pixel); only the selected rows
  * are written.  Optional per-pixel taps (full-image sized, may be NULL):
- *   tap_cell_flag : x | y<<8 | z<<16 | flag<<24  (flag: 0 miss, 1 hit, 2 oob; cell is 0 unless hit)
+ *   tap_cell_flag : x | y<<8 | z<<16 | flag<<24  (flag: 0 miss, 1 hit, 2 oob; cell is 0 unless hit);
+ *                   the wide build packs x | y<<10 | z<<20 | flag<<30
  *   tap_t         : RayRes.t (0 for oob)
  *   tap_checked   : RayRes.checked_nodes
  *   tap_node      : heap index of the hit leaf (0 unless hit) */
-int vro_render_rows(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], const float src[3],
+int vro_render_rows(const uint32_t *nodes, uint64_t n_slots, const coord_t root_dim[3], const float src[3],
                     const float forw[3], const float up[3], uint32_t width, uint32_t height, float viewport_width,
                     uint8_t iso, uint32_t row_begin, uint32_t row_end, uint8_t *rgb24, vro_render_stats *stats,
                     uint32_t *tap_cell_flag, float *tap_t, uint32_t *tap_checked, uint32_t *tap_node)
@@ -520,8 +540,13 @@ int vro_render_rows(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_
             st.escape_help_events += (uint64_t)r.escape_help_count;
             st.moves += r.moves;
             if (r.checked_nodes > st.max_checked_per_ray) st.max_checked_per_ray = r.checked_nodes;
+#ifdef VRO_WIDE
+            if (tap_cell_flag)
+                tap_cell_flag[pix] = (uint32_t)r.cell[0] | ((uint32_t)r.cell[1] << 10) | ((uint32_t)r.cell[2] << 20) | (flag << 30);
+#else
             if (tap_cell_flag)
                 tap_cell_flag[pix] = (uint32_t)r.cell[0] | ((uint32_t)r.cell[1] << 8) | ((uint32_t)r.cell[2] << 16) | (flag << 24);
+#endif
             if (tap_t) tap_t[pix] = r.oob ? 0.0f : r.t;
             if (tap_checked) tap_checked[pix] = (uint32_t)r.checked_nodes;
             if (tap_node) tap_node[pix] = r.hit ? r.node_idx : 0;
@@ -532,7 +557,7 @@ int vro_render_rows(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_
     return VRO_OK;
 }
 
-int vro_render_image(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], const float src[3],
+int vro_render_image(const uint32_t *nodes, uint64_t n_slots, const coord_t root_dim[3], const float src[3],
                      const float forw[3], const float up[3], uint32_t width, uint32_t height, float viewport_width,
                      uint8_t iso, uint8_t *rgb24, vro_render_stats *stats, uint32_t *tap_cell_flag, float *tap_t,
                      uint32_t *tap_checked, uint32_t *tap_node)

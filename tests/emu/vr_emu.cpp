@@ -179,3 +179,57 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
     if (traces_out) *traces_out = traces;
     return 0;
 }
+
+/* ---- wide volumes: the path-cache traversal of vr_trace_wide.h on wide node words ---- */
+#include "../../volumerenderer_amd/csrc/vr_trace_wide.h"
+
+namespace {
+struct HostPath {
+    uint32_t word[VR_MAX_DEPTH];
+    uint32_t get(uint32_t d) const { return word[d]; }
+    void set(uint32_t d, uint32_t w) { word[d] = w; }
+};
+} // namespace
+
+extern "C" int vr_emu_wide(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3], const float src[3],
+                           const float forw[3], const float up[3], uint32_t width, uint32_t height,
+                           float viewport_width, uint32_t iso, uint8_t *rgb, uint32_t *cell_flag, float *t_out,
+                           uint32_t *checked, uint32_t *node, uint64_t *sums /*7*/)
+{
+    VrViewK k;
+    k.ox = src[0]; k.oy = src[1]; k.oz = src[2];
+    k.fx = forw[0]; k.fy = forw[1]; k.fz = forw[2];
+    k.ux = up[0]; k.uy = up[1]; k.uz = up[2];
+    k.rx = k.fy * k.uz - k.fz * k.uy;
+    k.ry = k.fz * k.ux - k.fx * k.uz;
+    k.rz = k.fx * k.uy - k.fy * k.ux;
+    k.pixel_size = viewport_width / (float)width;
+    k.half_w = (float)(width / 2);
+    k.half_h = (float)(height / 2);
+    k.width = width; k.height = height;
+    k.rdx = root_dim[0]; k.rdy = root_dim[1]; k.rdz = root_dim[2];
+    k.root_hi = 0;
+    k.n_slots = n_slots;
+    std::memset(sums, 0, 7 * sizeof(uint64_t));
+    for (uint32_t yi = 0; yi < height; yi++)
+        for (uint32_t xi = 0; xi < width; xi++) {
+            VrRay ray = vr_make_ray(k, xi, yi);
+            HostPath path;
+            VrHit h = vr_trace_wide(k, ray, iso, HostFetch{ nodes }, path);
+            uint64_t pix = (uint64_t)yi * width + xi;
+            uint8_t g = h.flag == 1u ? vr_shade(h.t) : 0;
+            rgb[pix * 3] = rgb[pix * 3 + 1] = rgb[pix * 3 + 2] = g;
+            cell_flag[pix] = h.cell | (h.flag << VR_WIDE_FLAG_SHIFT);
+            t_out[pix] = h.flag == 2u ? 0.0f : h.t;
+            checked[pix] = h.checked;
+            node[pix] = h.node;
+            sums[0] += h.checked;
+            sums[1] += h.flag == 1u;
+            sums[2] += h.flag == 0u;
+            sums[3] += h.flag == 2u;
+            sums[4] += h.escapes;
+            sums[5] += h.moves;
+            sums[6] += h.error;
+        }
+    return 0;
+}

@@ -39,6 +39,23 @@ def emu_render(L, variant, nodes, rd, pos, f, u, w, h, vp, iso):
     return {"rgb": rgb, "cell_flag": cf, "t": tt, "checked": ck, "node": nd, "sums": sums}
 
 
+def emu_wide(L, nodes, rd, pos, f, u, w, h, vp, iso):
+    """The path-cache traversal of wide volumes (vr_trace_wide.h) on the CPU, on wide node words."""
+    rgb = np.zeros((h, w, 3), np.uint8)
+    cf = np.zeros((h, w), np.uint32)
+    tt = np.zeros((h, w), np.float32)
+    ck = np.zeros((h, w), np.uint32)
+    nd = np.zeros((h, w), np.uint32)
+    sums = np.zeros(7, np.uint64)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+    L.vr_emu_wide(C.c_void_p(nodes.ctypes.data), C.c_uint64(len(nodes)), (C.c_uint16 * 3)(*[int(x) for x in rd]),
+                  f3(pos), f3(f), f3(u), C.c_uint32(w), C.c_uint32(h), C.c_float(vp), C.c_uint32(iso),
+                  C.c_void_p(rgb.ctypes.data), C.c_void_p(cf.ctypes.data), C.c_void_p(tt.ctypes.data),
+                  C.c_void_p(ck.ctypes.data), C.c_void_p(nd.ctypes.data), C.c_void_p(sums.ctypes.data))
+    return {"rgb": rgb, "cell_flag": cf, "t": tt, "checked": ck, "node": nd, "sums": sums}
+
+
 def emu_sweep(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, chunk=0, max_trips=64):
     """The iso sweep with traversals shared between iso values, on the CPU (tests/emu/vr_emu.cpp)."""
     n_slots = len(nodes)

@@ -1,0 +1,190 @@
+"""GPU parity for volumes beyond the reference's u8 coordinates (up to 1024 voxels per axis).
+
+No reference artefact exists for such volumes (SPACESIZE = u8, src/typedef.zig:1): parity is UNPINNED beyond
+what these tests tie together -- the wide kernel equals the pinned u8 path (oracle and the reference's own
+renders) on volumes both can represent, and equals the u16 build of the same oracle file on wide volumes.
+At the full 1024^3 size the oracle cannot run; size-independent properties stand in."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import volumerenderer_amd as vr
+from volumerenderer_amd import capi, datasets
+from helpers import assert_same_render, random_volume
+from test_wide_cpu import WIDE_SHAPES, narrow_to_wide_cell_flag, narrow_to_wide_words
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(renderer, pos, forw, up, w, h, vp, iso):
+    img = vr.Image(w, h)
+    res = renderer.renderImage(pos, forw, up, img, vp, iso, taps=True)
+    res["rgb"] = img.pixels
+    return res
+
+
+def test_wide_kernel_on_c60_matches_reference_renders_and_u8_oracle(oracle, c60_vox, c60_tree, golden_gray):
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    with vr.Renderer(0) as r:
+        r.upload_kdt(vr.SlimKDT(narrow_to_wide_words(nodes), rd, wide=True))
+        out = r.renderSweep(pos, forw, up, 512, 512, 2.0, 0, 256)
+        for iso in range(256):
+            assert (out["rgb"][iso][:, :, 0] == golden_gray[iso]).all(), iso
+        for iso in (30, 100, 200):
+            ref = oracle.render(nodes, rd, pos, forw, up, 200, 160, 2.0, iso)
+            ref["cell_flag"] = narrow_to_wide_cell_flag(ref["cell_flag"])
+            got = _gpu(r, pos, forw, up, 200, 160, 2.0, iso)
+            assert_same_render(got, ref, "wide kernel on C60 iso %d" % iso)
+            assert got["stats"]["nodes_checked"] == ref["stats"].nodes_checked and got["stats"]["errors"] == 0
+
+
+@pytest.mark.parametrize("shape,kind", WIDE_SHAPES + [((1024, 5, 3), "smooth"), ((400, 300, 3), "noise")])
+def test_wide_volumes_gpu_build_and_render_match_wide_oracle(oracle, shape, kind):
+    rng = np.random.default_rng(sum(shape))
+    vox = random_volume(rng, shape, kind)
+    nodes, rd, st = oracle.build_kdt(vox, wide=True)
+    with vr.Renderer(0) as r:
+        r.upload_volume(vr.Data(vox))
+        bs = r.build_kdt("AlwaysCenter")
+        assert (bs.number_of_nodes, bs.layer_count, bs.non_center_partition_count) == (st.number_of_nodes, st.layer_count, 0)
+        got_nodes, got_rd, n_dev = r.download_kdt_wide()
+        assert (got_rd == rd).all() and n_dev == len(got_nodes)
+        m = min(len(nodes), len(got_nodes))
+        assert (got_nodes[:m] == nodes[:m]).all() and not got_nodes[m:].any() and not nodes[m:].any()
+        window, _, _ = r.download_kdt_wide(3, 5)
+        assert (window == nodes[3:8]).all()
+        cams = [(-30.0, -300.0, -30.0), (float(shape[0]) + 40.0, 20.0, 10.0), (8.0, 8.0, -320.0)]
+        for pos in cams:
+            pos, forw, up = oracle.main_camera(shape, pos)
+            for vp, iso in ((0.2, 0), (3.0, 90), (0.7, 200)):
+                ref = oracle.render(nodes, rd, pos, forw, up, 70, 50, vp, iso, wide=True)
+                got = _gpu(r, pos, forw, up, 70, 50, vp, iso)
+                assert_same_render(got, ref, "%s %s iso %d" % (shape, pos, iso))
+                s = got["stats"]
+                assert (s["nodes_checked"], s["hit_count"], s["miss_count"], s["oob_count"], s["moves"], s["errors"]) == (
+                    ref["stats"].nodes_checked, ref["stats"].hit_count, ref["stats"].miss_count, ref["stats"].oob_count,
+                    ref["stats"].moves, 0)
+        # the uploaded form of the same tree renders the same
+        pos, forw, up = oracle.main_camera(shape)
+        a = _gpu(r, pos, forw, up, 64, 64, 1.0, 120)
+        r.upload_kdt(vr.SlimKDT(nodes, rd, wide=True))
+        b = _gpu(r, pos, forw, up, 64, 64, 1.0, 120)
+        assert_same_render(b, a, "uploaded vs built")
+
+
+def test_wide_sweep_and_row_shards(oracle):
+    import torch
+    from volumerenderer_amd import sharding
+    vox = random_volume(np.random.default_rng(3), (520, 40, 36), "smooth")
+    nodes, rd, _ = oracle.build_kdt(vox, wide=True)
+    pos, forw, up = oracle.main_camera(vox.shape)
+    W, H = 150, 90
+    L = capi.lib()
+    with vr.Renderer(0) as r:
+        r.upload_kdt(vr.SlimKDT(nodes, rd, wide=True))
+        out = r.renderSweep(pos, forw, up, W, H, 2.5, 96, 6, taps=True)
+        for j in range(6):
+            ref = oracle.render(nodes, rd, pos, forw, up, W, H, 2.5, 96 + j, wide=True)
+            got = {k: out[k][j] for k in ("rgb", "cell_flag", "t", "checked", "node")}
+            assert_same_render(got, ref, "wide sweep iso %d" % (96 + j))
+            assert out["stats"][j]["nodes_checked"] == ref["stats"].nodes_checked
+        v = vr.raytrace._view(pos, forw, up, W, H, 2.5)
+        total = 0
+        for rank in range(3):
+            r0, r1 = sharding.row_shard(rank, 3, H)
+            d_rgb = torch.zeros((6, r1 - r0, W, 3), dtype=torch.uint8, device="cuda")
+            d_stats = torch.zeros((6, 7), dtype=torch.int64, device="cuda")
+            capi.check(L.vr_render_device(r.handle, C.byref(v), 96, 6, r0, r1, d_rgb.data_ptr(), d_stats.data_ptr(), None,
+                                          None), "vr_render_device")
+            capi.check(L.vr_sync(r.handle), "vr_sync")
+            assert (d_rgb.cpu().numpy() == out["rgb"][:, r0:r1]).all(), rank
+            total += int(d_stats.cpu().numpy()[:, 0].sum())
+        assert total == sum(s["nodes_checked"] for s in out["stats"])
+
+
+def test_wide_malformed_tree_ends_every_ray(oracle):
+    rng = np.random.default_rng(5)
+    nodes = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
+    pos, forw, up = oracle.main_camera((301, 201, 101))
+    with vr.Renderer(0) as r:
+        r.upload_kdt(vr.SlimKDT(nodes, np.array([300, 200, 100]), wide=True))
+        out = r.renderSweep(pos, forw, up, 64, 64, 2.0, 100, 1)
+        s = out["stats"][0]
+        assert s["hit_count"] + s["miss_count"] + s["oob_count"] == 64 * 64
+
+
+def test_wide_argument_checks():
+    L = capi.lib()
+    with vr.Renderer(0) as r:
+        vox = np.zeros((2, 2, 1025), np.uint8)
+        assert L.vr_upload_volume(r.handle, vox.ctypes.data, 2, 2, 1025) == capi.VR_EARG
+        vox = np.zeros((300, 4, 4), np.uint8)
+        r.upload_volume(vr.Data(vox))
+        assert L.vr_build_kdt(r.handle, capi.HEURISTICS["MinimizeSpan"], None) == capi.VR_EARG  # centre split only
+        r.build_kdt("AlwaysCenter")
+        n = C.c_uint64()
+        assert L.vr_download_kdt(r.handle, None, 0, C.byref(n), None) == capi.VR_ESTATE  # wide tree: other call
+        rd = (C.c_uint16 * 3)(1024, 4, 4)
+        one = np.ones(8, np.uint32)
+        assert L.vr_upload_kdt_wide(r.handle, one.ctypes.data, 8, rd) == capi.VR_EARG
+
+
+def test_gyroid_1024_cubed_full_size_properties():
+    """The 1024^3 stress configuration at full size: 2^31-slot tree built on the GPU (8 GiB), 4096 x 4096
+    frame.  The CPU oracle cannot run at this size; checked instead: node count, the root's range = range of
+    the whole volume, every hit cell's 8 voxel corners bracket the iso value and equal the hit leaf's stored
+    range, 4 row shards = the whole frame with the same counters, a two-iso call = two one-iso calls."""
+    import torch
+    from volumerenderer_amd import sharding
+    n = 1024
+    vox = datasets.gyroid_noise(n)
+    L = capi.lib()
+    with vr.Renderer(0) as r:
+        r.upload_volume(vr.Data(vox))
+        bs = r.build_kdt("AlwaysCenter")
+        assert bs.number_of_nodes == 2 * (n - 1) ** 3 - 1 and bs.layer_count == 30
+        root, rd, n_dev = r.download_kdt_wide(0, 1)
+        assert n_dev == 2 ** 31 and (rd == n - 1).all()
+        assert (int(root[0]) & 0xff, (int(root[0]) >> 8) & 0xff) == (int(vox.min()), int(vox.max()))
+        assert (int(root[0]) >> 16) & 0xfff == (n - 1) // 2 and (int(root[0]) >> 28) & 3 == 2
+        pos, forw, up = vr.main_camera(vox.shape)
+        W = H = 4096
+        iso = 140
+        whole = r.renderSweep(pos, forw, up, W, H, 2.0, iso, 1, taps=True)
+        ws = whole["stats"][0]
+        assert ws["errors"] == 0 and ws["hit_count"] > 100000
+        assert ws["hit_count"] + ws["miss_count"] + ws["oob_count"] == W * H
+        cf = whole["cell_flag"][0]
+        hit = (cf >> 30) == capi.FLAG_HIT
+        assert int(hit.sum()) == ws["hit_count"]
+        x, y, z = (cf[hit] & 1023).astype(np.int64), ((cf[hit] >> 10) & 1023).astype(np.int64), ((cf[hit] >> 20) & 1023).astype(np.int64)
+        corners = np.stack([vox[x + (k & 1), y + ((k >> 1) & 1), z + (k >> 2)] for k in range(8)])
+        assert (corners.min(0) <= iso).all() and (iso <= corners.max(0)).all()
+        leaf = whole["node"][0][hit]
+        pick = np.random.default_rng(0).choice(len(leaf), 64, replace=False)
+        for j in pick:
+            word, _, _ = r.download_kdt_wide(int(leaf[j]), 1)
+            assert (int(word[0]) & 0xff, (int(word[0]) >> 8) & 0xff) == (int(corners[:, j].min()), int(corners[:, j].max()))
+        # rays that hit carry t inside the shading window or beyond it; pixels follow src/raytrace.zig:56-61
+        t = whole["t"][0][hit]
+        g = 255 - np.clip(np.trunc(np.minimum(200.0, t - np.float32(300.0))), 0, 255).astype(np.uint8)
+        assert (whole["rgb"][0][hit][:, 0] == g).all() and not whole["rgb"][0][~hit].any()
+        v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+        stats = np.zeros(7, np.int64)
+        for rank in range(4):
+            r0, r1 = sharding.row_shard(rank, 4, H)
+            d_rgb = torch.zeros((1, r1 - r0, W, 3), dtype=torch.uint8, device="cuda")
+            d_stats = torch.zeros((1, 7), dtype=torch.int64, device="cuda")
+            capi.check(L.vr_render_device(r.handle, C.byref(v), iso, 1, r0, r1, d_rgb.data_ptr(), d_stats.data_ptr(), None,
+                                          None), "vr_render_device")
+            capi.check(L.vr_sync(r.handle), "vr_sync")
+            assert (d_rgb.cpu().numpy()[0] == whole["rgb"][0, r0:r1]).all(), rank
+            stats += d_stats.cpu().numpy()[0]
+        assert [int(s) for s in stats] == [ws[k] for k in ("nodes_checked", "hit_count", "miss_count", "oob_count",
+                                                            "escape_help_events", "moves", "errors")]
+        two = r.renderSweep(pos, forw, up, 1024, 1024, 2.0, iso, 2)
+        for j in range(2):
+            one = r.renderSweep(pos, forw, up, 1024, 1024, 2.0, iso + j, 1)
+            assert (one["rgb"][0] == two["rgb"][j]).all() and one["stats"][0] == two["stats"][j]

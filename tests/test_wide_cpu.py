@@ -1,0 +1,91 @@
+"""Volumes beyond the reference's u8 coordinates (up to 1024 voxels per axis), on the CPU.
+
+No reference artefact exists for such volumes (SPACESIZE = u8, src/typedef.zig:1).  The wide oracle is
+the same C file built with u16 coordinates; these tests tie it to the pinned u8 oracle wherever both
+apply, and tie the product's wide lane code (vr_trace_wide.h, run on the CPU) to the wide oracle.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_same_render, emu_wide, random_volume
+
+
+def narrow_to_wide_words(nodes):
+    """SlimNode word (partition 8 bits, axis at bit 24) -> wide node word (partition 12 bits, axis at bit 28)."""
+    nodes = nodes.astype(np.uint32)
+    return (nodes & np.uint32(0x00ffffff)) | (((nodes >> np.uint32(24)) & np.uint32(3)) << np.uint32(28))
+
+
+def narrow_to_wide_cell_flag(cf):
+    x, y, z, flag = cf & 0xff, (cf >> 8) & 0xff, (cf >> 16) & 0xff, cf >> 24
+    return (x | (y << 10) | (z << 20) | (flag << 30)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("heuristic", ["AlwaysCenter", "FlexibleFirst5", "FlexibleCenterWeighted100"])
+def test_wide_oracle_equals_u8_oracle_on_c60(oracle, c60_vox, heuristic):
+    vox = c60_vox if heuristic == "AlwaysCenter" else c60_vox[20:40, 18:40, 20:38]
+    n8, rd8, st8 = oracle.build_kdt(vox, heuristic)
+    nw, rdw, stw = oracle.build_kdt(vox, heuristic, wide=True)
+    assert (rd8 == rdw).all() and len(n8) == len(nw)
+    assert (narrow_to_wide_words(n8) == nw).all()
+    assert (st8.number_of_nodes, st8.layer_count, st8.non_center_partition_count) == (
+        stw.number_of_nodes, stw.layer_count, stw.non_center_partition_count)
+    pos, forw, up = oracle.main_camera(vox.shape)
+    for iso in (0, 60, 100, 255):
+        a = oracle.render(n8, rd8, pos, forw, up, 96, 96, 2.0, iso)
+        b = oracle.render(nw, rdw, pos, forw, up, 96, 96, 2.0, iso, wide=True)
+        a["cell_flag"] = narrow_to_wide_cell_flag(a["cell_flag"])
+        assert_same_render(b, a, "wide oracle vs u8 oracle, %s iso %d" % (heuristic, iso))
+        assert a["stats"].nodes_checked == b["stats"].nodes_checked
+
+
+def test_wide_oracle_reproduces_the_reference_renders(oracle, c60_vox, golden_gray):
+    """The wide build against the reference's own renders/out_iso{d}.png (C60, 512 x 512)."""
+    nw, rdw, _ = oracle.build_kdt(c60_vox, wide=True)
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    for iso in (0, 57, 100, 140, 255):
+        got = oracle.render(nw, rdw, pos, forw, up, 512, 512, 2.0, iso, wide=True, taps=False)
+        assert (got["rgb"][:, :, 0] == golden_gray[iso]).all()
+
+
+WIDE_SHAPES = [((300, 9, 7), "noise"), ((5, 700, 6), "smooth"), ((4, 6, 1024), "sparse"), ((260, 4, 258), "noise")]
+
+
+@pytest.mark.parametrize("shape,kind", WIDE_SHAPES)
+def test_wide_lane_code_matches_wide_oracle(oracle, emu_lib, shape, kind):
+    rng = np.random.default_rng(sum(shape))
+    vox = random_volume(rng, shape, kind)
+    nodes, rd, st = oracle.build_kdt(vox, wide=True)
+    assert int(rd.max()) > 255
+    cams = [(-30.0, -300.0, -30.0), (float(shape[0]) + 40.0, 20.0, 10.0), (8.0, 8.0, -320.0)]
+    hits = 0
+    for pos in cams:
+        pos, forw, up = oracle.main_camera(shape, pos)
+        for vp in (0.2, 3.0):
+            for iso in (0, 90, 200):
+                ref = oracle.render(nodes, rd, pos, forw, up, 48, 40, vp, iso, wide=True)
+                got = emu_wide(emu_lib, nodes, rd, pos, forw, up, 48, 40, vp, iso)
+                assert_same_render(got, ref, "%s %s iso %d" % (shape, pos, iso))
+                assert int(got["sums"][0]) == ref["stats"].nodes_checked and int(got["sums"][6]) == 0
+                hits += ref["stats"].hit_count
+    assert hits > 0
+
+
+def test_wide_lane_code_on_c60_equals_u8_oracle(oracle, emu_lib, c60_vox, c60_tree):
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    for iso in (30, 100, 180):
+        ref = oracle.render(nodes, rd, pos, forw, up, 128, 128, 2.0, iso)
+        ref["cell_flag"] = narrow_to_wide_cell_flag(ref["cell_flag"])
+        got = emu_wide(emu_lib, narrow_to_wide_words(nodes), rd.astype(np.uint16), pos, forw, up, 128, 128, 2.0, iso)
+        assert_same_render(got, ref, "wide lane code on C60 iso %d" % iso)
+
+
+def test_wide_lane_code_survives_malformed_trees(oracle, emu_lib):
+    """Random words as a tree: every ray must end (error flagged or not) without leaving the array."""
+    rng = np.random.default_rng(5)
+    nodes = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
+    rd = np.array([300, 200, 100], np.uint16)
+    pos, forw, up = oracle.main_camera((301, 201, 101))
+    got = emu_wide(emu_lib, nodes, rd, pos, forw, up, 32, 32, 2.0, 100)
+    assert int(got["sums"][1] + got["sums"][2] + got["sums"][3]) == 32 * 32

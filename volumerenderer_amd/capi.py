@@ -36,7 +36,7 @@ HEURISTICS = {
 # every symbol include/vr.h declares; tests check that the library exports each of them
 EXPORTS = [
     "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_alloc_host", "vr_free_host", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
-    "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_render",
+    "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_upload_kdt_wide", "vr_download_kdt_wide", "vr_render",
     "vr_render_sweep", "vr_render_device", "vr_sync", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
 ]
@@ -111,6 +111,9 @@ def lib():
     L.vr_upload_kdt.argtypes = [vp, vp, C.c_uint64, u8p]
     L.vr_build_kdt.argtypes = [vp, C.c_int, C.POINTER(BuildStats)]
     L.vr_download_kdt.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64), u8p]
+    u16p = C.POINTER(C.c_uint16)
+    L.vr_upload_kdt_wide.argtypes = [vp, vp, C.c_uint64, u16p]
+    L.vr_download_kdt_wide.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), u16p]
     L.vr_render.argtypes = [vp, C.POINTER(View), C.c_uint8, vp, C.POINTER(RenderStats), C.POINTER(Taps)]
     L.vr_render_sweep.argtypes = [vp, C.POINTER(View), C.c_uint32, C.c_uint32, vp, C.POINTER(RenderStats),
                                   C.POINTER(Taps)]

@@ -14,6 +14,11 @@
  *      parent's voxels).
  * Both the reference-format array and the flattened array the render kernels walk are written.
  * HBM-bound integer work: 8 bytes written per slot, 8 voxel bytes read per leaf.
+ *
+ * WIDE = true builds the tree of a volume beyond the reference's u8 coordinates (up to 1024 voxels per
+ * axis) in the wide node word of vr_trace_wide.h (12-bit partition, axis at bit 28); only that one array
+ * is written.  No node word of either format is 0 (an inner node's partition is at least 1, a leaf's
+ * axis is 2), so 0 marks an empty slot, and a node whose first child slot is empty is a leaf.
  */
 #include "vr_internal.h"
 
@@ -31,6 +36,7 @@ struct Box3 {
     }
 };
 
+template <bool WIDE>
 __global__ __launch_bounds__(256) void vr_k_build_structure(const uint8_t *__restrict__ vox, uint32_t rx, uint32_t ry,
                                                            uint32_t rz, uint64_t n_slots, uint32_t *__restrict__ raw,
                                                            uint32_t *__restrict__ prepared)
@@ -69,27 +75,35 @@ __global__ __launch_bounds__(256) void vr_k_build_structure(const uint8_t *__res
                 mx = v > mx ? v : mx;
             }
         }
-        w_raw = mn | (mx << 8) | (part << 16) | ((uint32_t)a << 24);
+        w_raw = mn | (mx << 8) | (part << 16) | ((uint32_t)a << (WIDE ? 28 : 24));
         w_prep = mn | (mx << 8) | (part << 16) | (leaf ? 0x80000000u : ((uint32_t)a * 10u) << 24);
     }
     raw[idx] = w_raw;
-    prepared[idx + 1] = w_prep;
-    if (idx == 0) prepared[0] = 0;
+    if (!WIDE) {
+        prepared[idx + 1] = w_prep;
+        if (idx == 0) prepared[0] = 0;
+    }
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(256) void vr_k_build_ranges(uint64_t first, uint64_t count, uint32_t *__restrict__ raw,
                                                         uint32_t *__restrict__ prepared)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint64_t idx = first + i;
-    const uint32_t p = prepared[idx + 1];
-    if (p == 0u || (p & 0x80000000u)) return; /* empty slot or leaf */
+    uint32_t p = 0;
+    if (WIDE) {
+        if (raw[idx] == 0u || raw[2 * idx + 1] == 0u) return; /* empty slot or leaf */
+    } else {
+        p = prepared[idx + 1];
+        if (p == 0u || (p & 0x80000000u)) return; /* empty slot or leaf */
+    }
     const uint32_t c1 = raw[2 * idx + 1], c2 = raw[2 * idx + 2];
     const uint32_t mn1 = c1 & 0xffu, mn2 = c2 & 0xffu, mx1 = (c1 >> 8) & 0xffu, mx2 = (c2 >> 8) & 0xffu;
     const uint32_t r = (mn1 < mn2 ? mn1 : mn2) | ((mx1 > mx2 ? mx1 : mx2) << 8);
     raw[idx] = (raw[idx] & 0xffff0000u) | r;
-    prepared[idx + 1] = (p & 0xffff0000u) | r;
+    if (!WIDE) prepared[idx + 1] = (p & 0xffff0000u) | r;
 }
 
 uint32_t ceil_log2(uint32_t v)
@@ -111,12 +125,22 @@ hipError_t vr_launch_build_center(hipStream_t stream, const uint8_t *d_vox, uint
                                   uint32_t depth, uint32_t *d_raw, uint32_t *d_prepared)
 {
     const uint64_t n_slots = (uint64_t)1 << (depth + 1);
-    hipLaunchKernelGGL(vr_k_build_structure, dim3((uint32_t)((n_slots + 255u) / 256u)), dim3(256), 0, stream, d_vox, rx, ry,
+    if (!d_prepared) { /* wide node words, one array */
+        hipLaunchKernelGGL(vr_k_build_structure<true>, dim3((uint32_t)((n_slots + 255u) / 256u)), dim3(256), 0, stream, d_vox,
+                           rx, ry, rz, n_slots, d_raw, (uint32_t *)nullptr);
+        for (int level = (int)depth - 1; level >= 0; level--) {
+            const uint64_t first = ((uint64_t)1 << level) - 1u, count = (uint64_t)1 << level;
+            hipLaunchKernelGGL(vr_k_build_ranges<true>, dim3((uint32_t)((count + 255u) / 256u)), dim3(256), 0, stream, first,
+                               count, d_raw, (uint32_t *)nullptr);
+        }
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(vr_k_build_structure<false>, dim3((uint32_t)((n_slots + 255u) / 256u)), dim3(256), 0, stream, d_vox, rx, ry,
                        rz, n_slots, d_raw, d_prepared);
     for (int level = (int)depth - 1; level >= 0; level--) {
         const uint64_t first = ((uint64_t)1 << level) - 1u, count = (uint64_t)1 << level;
-        hipLaunchKernelGGL(vr_k_build_ranges, dim3((uint32_t)((count + 255u) / 256u)), dim3(256), 0, stream, first, count,
-                           d_raw, d_prepared);
+        hipLaunchKernelGGL(vr_k_build_ranges<false>, dim3((uint32_t)((count + 255u) / 256u)), dim3(256), 0, stream, first,
+                           count, d_raw, d_prepared);
     }
     return hipGetLastError();
 }

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "vr_internal.h"
+#include "vr_trace_wide.h"
 
 #define VR_HIP(call)                                           \
     do {                                                       \
@@ -30,7 +31,8 @@ struct vr_ctx {
     void *d_prepared_raw = nullptr;   /* the allocation d_prepared lies in                     */
     uint64_t n_slots = 0;
     uint32_t max_depth = 0;
-    uint8_t root_dim[3] = { 0, 0, 0 };
+    uint32_t root_dim[3] = { 0, 0, 0 };
+    bool wide = false; /* d_nodes holds wide node words (a volume beyond 256 voxels per axis); no flattened form */
     int n_cus = 0;
     /* scratch of the pipeline kernels, grown on demand */
     void *d_work = nullptr;
@@ -181,14 +183,19 @@ void vr_ctx_destroy(vr_ctx *c)
 
 int vr_upload_volume(vr_ctx *c, const uint8_t *vox, uint32_t rx, uint32_t ry, uint32_t rz)
 {
-    if (!c || !vox || rx < 2 || ry < 2 || rz < 2 || rx > 256 || ry > 256 || rz > 256) return VR_EARG;
+    if (!c || !vox || rx < 2 || ry < 2 || rz < 2) return VR_EARG;
+    if (rx > VR_WIDE_MAX_RES || ry > VR_WIDE_MAX_RES || rz > VR_WIDE_MAX_RES) return VR_EARG;
     VR_HIP(hipSetDevice(c->device));
     const size_t n = (size_t)rx * ry * rz;
     if (c->d_vox) { VR_HIP(hipFree(c->d_vox)); c->d_vox = nullptr; }
     std::free(c->h_vox);
-    c->h_vox = (uint8_t *)std::malloc(n);
-    if (!c->h_vox) return VR_ENOMEM;
-    std::memcpy(c->h_vox, vox, n);
+    c->h_vox = nullptr;
+    c->res[0] = c->res[1] = c->res[2] = 0;
+    if (rx <= 256 && ry <= 256 && rz <= 256) { /* the host builder of the span heuristics reads this copy */
+        c->h_vox = (uint8_t *)std::malloc(n);
+        if (!c->h_vox) return VR_ENOMEM;
+        std::memcpy(c->h_vox, vox, n);
+    }
     VR_HIP(hipMalloc((void **)&c->d_vox, n));
     VR_HIP(hipMemcpy(c->d_vox, vox, n, hipMemcpyHostToDevice));
     c->res[0] = rx; c->res[1] = ry; c->res[2] = rz;
@@ -220,14 +227,63 @@ int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint
     c->n_slots = n_slots;
     c->max_depth = max_depth;
     c->root_dim[0] = root_dim[0]; c->root_dim[1] = root_dim[1]; c->root_dim[2] = root_dim[2];
+    c->wide = false;
+    return VR_OK;
+}
+
+int vr_upload_kdt_wide(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3])
+{
+    if (!c || !nodes || !n_slots || !root_dim) return VR_EARG;
+    if (n_slots > ((uint64_t)1 << 32)) return VR_EARG;
+    for (int a = 0; a < 3; a++)
+        if (root_dim[a] == 0 || root_dim[a] >= VR_WIDE_MAX_RES) return VR_EARG;
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
+    free_prepared(c);
+    c->n_slots = 0;
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_nodes, n_slots * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
+    c->n_slots = n_slots;
+    c->max_depth = VR_MAX_DEPTH; /* not walked on the host: the kernel checks index, depth and axis as it goes */
+    for (int a = 0; a < 3; a++) c->root_dim[a] = root_dim[a];
+    c->wide = true;
     return VR_OK;
 }
 
 int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
 {
     if (!c) return VR_EARG;
-    if (!c->h_vox || !c->d_vox) return VR_ESTATE;
+    if (!c->d_vox) return VR_ESTATE;
     if (heuristic < 0 || heuristic >= VR_H_COUNT) return VR_EARG;
+    const bool wide = c->res[0] > 256 || c->res[1] > 256 || c->res[2] > 256;
+    if (wide) {
+        /* beyond the reference's coordinate range: centre split only, built on the device in wide node words */
+        if (heuristic != VR_H_ALWAYS_CENTER) return VR_EARG;
+        const uint32_t depth = vr_center_tree_depth(c->res[0], c->res[1], c->res[2]);
+        if (depth >= VR_MAX_DEPTH + 1u) return VR_ETOODEEP;
+        const uint64_t n_slots = (uint64_t)1 << (depth + 1);
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
+        free_prepared(c);
+        c->n_slots = 0;
+        if (e == hipSuccess) e = hipMalloc((void **)&c->d_nodes, n_slots * sizeof(uint32_t));
+        if (e == hipSuccess) e = vr_launch_build_center(c->stream, c->d_vox, c->res[0], c->res[1], c->res[2], depth, c->d_nodes, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
+        c->n_slots = n_slots;
+        c->max_depth = depth;
+        for (int a = 0; a < 3; a++) c->root_dim[a] = c->res[a] - 1u;
+        c->wide = true;
+        if (stats_out) {
+            const uint64_t cells = (uint64_t)(c->res[0] - 1u) * (c->res[1] - 1u) * (c->res[2] - 1u);
+            stats_out->non_center_partition_count = 0;
+            stats_out->layer_count = depth;
+            stats_out->number_of_nodes = 2 * cells - 1;
+        }
+        return VR_OK;
+    }
+    if (!c->h_vox) return VR_ESTATE;
     if (heuristic != VR_H_ALWAYS_CENTER) {
         /* span heuristics: host builder, then the ordinary upload path */
         uint32_t *nodes = nullptr;
@@ -253,7 +309,8 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
     if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
     c->n_slots = n_slots;
     c->max_depth = depth;
-    for (int a = 0; a < 3; a++) c->root_dim[a] = (uint8_t)(c->res[a] - 1u);
+    for (int a = 0; a < 3; a++) c->root_dim[a] = c->res[a] - 1u;
+    c->wide = false;
     if (stats_out) {
         /* a full binary tree over the cells: 2 * cells - 1 nodes; every partition is the centre one */
         const uint64_t cells = (uint64_t)(c->res[0] - 1u) * (c->res[1] - 1u) * (c->res[2] - 1u);
@@ -267,13 +324,30 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
 int vr_download_kdt(vr_ctx *c, uint32_t *nodes_out, uint64_t cap_slots, uint64_t *n_slots_out, uint8_t root_dim_out[3])
 {
     if (!c) return VR_EARG;
-    if (!c->d_nodes) return VR_ESTATE;
+    if (!c->d_nodes || c->wide) return VR_ESTATE;
     if (n_slots_out) *n_slots_out = c->n_slots;
-    if (root_dim_out) { root_dim_out[0] = c->root_dim[0]; root_dim_out[1] = c->root_dim[1]; root_dim_out[2] = c->root_dim[2]; }
+    if (root_dim_out)
+        for (int a = 0; a < 3; a++) root_dim_out[a] = (uint8_t)c->root_dim[a];
     if (nodes_out) {
         if (cap_slots < c->n_slots) return VR_EARG;
         VR_HIP(hipSetDevice(c->device));
         VR_HIP(hipMemcpy(nodes_out, c->d_nodes, c->n_slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return VR_OK;
+}
+
+int vr_download_kdt_wide(vr_ctx *c, uint32_t *nodes_out, uint64_t first_slot, uint64_t n_slots, uint64_t *n_slots_out,
+                         uint16_t root_dim_out[3])
+{
+    if (!c) return VR_EARG;
+    if (!c->d_nodes || !c->wide) return VR_ESTATE;
+    if (n_slots_out) *n_slots_out = c->n_slots;
+    if (root_dim_out)
+        for (int a = 0; a < 3; a++) root_dim_out[a] = (uint16_t)c->root_dim[a];
+    if (nodes_out && n_slots) {
+        if (first_slot >= c->n_slots || n_slots > c->n_slots - first_slot) return VR_EARG;
+        VR_HIP(hipSetDevice(c->device));
+        VR_HIP(hipMemcpy(nodes_out, c->d_nodes + first_slot, n_slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return VR_OK;
 }
@@ -298,6 +372,23 @@ int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_
         taps.node = d_taps->node;
     }
     const int variant = c->variant;
+    if (c->wide) {
+        if (d_stats) VR_HIP(hipMemsetAsync(d_stats, 0, sizeof(vr_render_stats) * iso_count, s));
+        hipEvent_t w0 = nullptr, w1 = nullptr;
+        if (c->timing) {
+            while (c->ev.size() < c->ev_used + 2) {
+                hipEvent_t e;
+                VR_HIP(hipEventCreate(&e));
+                c->ev.push_back(e);
+            }
+            w0 = c->ev[c->ev_used];
+            w1 = c->ev[c->ev_used + 1];
+        }
+        VR_HIP(vr_launch_render_wide(s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
+                                     (vr_render_stats *)d_stats, taps, w0, w1));
+        if (c->timing) c->ev_used += 2;
+        return VR_OK;
+    }
     if (variant == VR_KERNEL_DEFAULT || variant == VR_KERNEL_PIPELINE || variant == VR_KERNEL_SWEEP) {
         /* growing the scratch is the only allocation on this path; it happens when a larger view comes */
         const size_t need = vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count);

@@ -28,3 +28,21 @@ def bonsai_standin(n=256, seed=1234):
     vol += 0.08 * np.repeat(np.repeat(np.repeat(coarse, k, 0), k, 1), k, 2)[:n, :n, :n]
     vol = np.clip(vol / vol.max(), 0.0, 1.0)
     return np.ascontiguousarray((vol * 255.0).astype(np.uint8))
+
+
+def gyroid_noise(n=1024, seed=42, periods=6.0, noise=24, shell=0.35):
+    """Deterministic n^3 u8 volume beyond the reference's coordinate range (its SPACESIZE is u8): a gyroid
+    shell -- density falls off with the distance |sin x cos y + sin y cos z + sin z cos x| from the gyroid
+    surface -- plus uniform noise of amplitude `noise`.  x slowest / z fastest like Data.data
+    (src/Data.zig:90-92).  Built slab by slab: the float intermediates never exceed one x-slab."""
+    rng = np.random.default_rng(seed)
+    w = np.float32(2.0 * np.pi * periods / n)
+    ax = np.arange(n, dtype=np.float32) * w
+    s, c = np.sin(ax), np.cos(ax)
+    out = np.empty((n, n, n), dtype=np.uint8)
+    yz = s[:, None] * c[None, :]  # sin y cos z
+    for i in range(n):
+        g = s[i] * c[:, None] + yz + s[None, :] * c[i]  # sin x cos y + sin y cos z + sin z cos x
+        d = np.clip(1.0 - np.abs(g) / np.float32(shell), 0.0, 1.0) * np.float32(255 - noise)
+        out[i] = d.astype(np.uint8) + rng.integers(0, noise + 1, (n, n), dtype=np.uint8)
+    return out

@@ -79,8 +79,13 @@ class Renderer:
         capi.check(self._L.vr_upload_volume(self._ctx, data.data.ctypes.data, rx, ry, rz), "vr_upload_volume")
 
     def upload_kdt(self, kdt):
-        rd = (C.c_uint8 * 3)(*[int(x) for x in kdt.root_dim])
-        capi.check(self._L.vr_upload_kdt(self._ctx, kdt.nodes.ctypes.data, len(kdt.nodes), rd), "vr_upload_kdt")
+        if getattr(kdt, "wide", False):
+            rd = (C.c_uint16 * 3)(*[int(x) for x in kdt.root_dim])
+            capi.check(self._L.vr_upload_kdt_wide(self._ctx, kdt.nodes.ctypes.data, len(kdt.nodes), rd),
+                       "vr_upload_kdt_wide")
+        else:
+            rd = (C.c_uint8 * 3)(*[int(x) for x in kdt.root_dim])
+            capi.check(self._L.vr_upload_kdt(self._ctx, kdt.nodes.ctypes.data, len(kdt.nodes), rd), "vr_upload_kdt")
         self.kdt = kdt
 
     def build_kdt(self, heuristic="AlwaysCenter"):
@@ -96,6 +101,18 @@ class Renderer:
         nodes = np.zeros(n.value, dtype=np.uint32)
         capi.check(self._L.vr_download_kdt(self._ctx, nodes.ctypes.data, n.value, C.byref(n), rd), "vr_download_kdt")
         return nodes, np.array(list(rd), dtype=np.uint8)
+
+    def download_kdt_wide(self, first_slot=0, n_slots=None):
+        """Slots [first_slot, first_slot + n_slots) of a wide tree (a volume beyond 256 voxels per axis):
+        returns (wide node words, root_dim uint16[3], array length on the device)."""
+        n = C.c_uint64()
+        rd = (C.c_uint16 * 3)()
+        capi.check(self._L.vr_download_kdt_wide(self._ctx, None, 0, 0, C.byref(n), rd), "vr_download_kdt_wide")
+        count = n.value - first_slot if n_slots is None else int(n_slots)
+        nodes = np.zeros(count, dtype=np.uint32)
+        capi.check(self._L.vr_download_kdt_wide(self._ctx, nodes.ctypes.data, int(first_slot), count, C.byref(n), rd),
+                   "vr_download_kdt_wide")
+        return nodes, np.array(list(rd), dtype=np.uint16), n.value
 
     def pinned_frames(self, iso_count, height, width):
         """uint8[iso_count, height, width, 3] in page-locked host memory (vr_alloc_host); the array keeps the

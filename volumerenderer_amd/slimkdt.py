@@ -11,9 +11,12 @@ class SlimKDT:
     """nodes: uint32 heap-indexed array of packed SlimNode words (src/SlimKDT.zig:9-13);
     root_dim: uint8[3] = resolution - 1 (:129-133); build: PartitionBuildData (:215-219)."""
 
-    def __init__(self, nodes, root_dim, build=None, data=None):
+    def __init__(self, nodes, root_dim, build=None, data=None, wide=False):
         self.nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
-        self.root_dim = np.ascontiguousarray(root_dim, dtype=np.uint8)
+        # wide: a volume beyond the reference's u8 coordinates; nodes are wide node words (12-bit partition, axis at
+        # bit 28) and root_dim is uint16
+        self.wide = bool(wide)
+        self.root_dim = np.ascontiguousarray(root_dim, dtype=np.uint16 if self.wide else np.uint8)
         self.build = build
         self.data = data
 
