@@ -7,7 +7,8 @@ reference camera (src/main.zig:31-43), i.e. 256 x 1 048 576 primary rays per ste
 rays count, including the ones that miss the volume -- the reference's ms/frame includes them too.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--gather]
-                    [--shard iso|rows] [--kernel V] [--width PX] [--volume skull|c60|standin256] [--no-cpu-baseline]
+                    [--shard iso|rows] [--kernel V] [--width PX] [--volume skull|c60|standin256|gyroid1024]
+                    [--iso-begin B] [--iso-count N] [--no-cpu-baseline]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`
 (one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE from the environment).  The path shards with no
@@ -46,10 +47,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
-def cpu_baseline(kdt, pos, forw, up, width, budget_s=20.0):
+def cpu_baseline(kdt, pos, forw, up, width, iso_begin=0, iso_count=256, budget_s=20.0):
     """Times the oracle's render_image (1 core) on every 4th iso of the sweep until the budget is spent."""
     from oracle import oracle as O
-    isos = list(range(0, 256, 4))
+    isos = list(range(iso_begin, iso_begin + iso_count, 4 if iso_count >= 8 else 1))
     done, rays, checks = [], 0, 0
     t0 = time.perf_counter()
     for iso in isos:
@@ -74,7 +75,7 @@ def cpu_baseline(kdt, pos, forw, up, width, budget_s=20.0):
             "nodes_checked_per_frame": checks / max(1, len(done))}
 
 
-def cpu_all_cores(kdt, pos, forw, up, width, threads, budget_s=8.0):
+def cpu_all_cores(kdt, pos, forw, up, width, threads, iso_begin=0, iso_count=256, budget_s=8.0):
     """The oracle with the rows of each frame spread over `threads` host threads (ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     import numpy as np
@@ -83,7 +84,7 @@ def cpu_all_cores(kdt, pos, forw, up, width, threads, budget_s=8.0):
     done, rays = [], 0
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as pool:
-        for iso in range(1, 256, 2):
+        for iso in range(iso_begin + (1 if iso_count > 1 else 0), iso_begin + iso_count, 2):
             img = np.zeros((width, width, 3), np.uint8)
             list(pool.map(lambda b: O.render(kdt.nodes, kdt.root_dim, pos, forw, up, width, width, 2.0, iso, rows=b,
                                              taps=False, out=img), bands))
@@ -136,7 +137,9 @@ def main():
     ap.add_argument("--gather", action="store_true")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--volume", choices=["skull", "c60", "standin256"], default="skull")
+    ap.add_argument("--volume", choices=["skull", "c60", "standin256", "gyroid1024"], default="skull")
+    ap.add_argument("--iso-begin", type=int, default=0)
+    ap.add_argument("--iso-count", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -167,29 +170,39 @@ def main():
     elif args.volume == "c60":
         data = vr.Data.loadUCD(os.path.join(ROOT, "tests", "data", "C60.vol"))
         what = "C60.vol shipped by the reference (64^3 u8), reference camera"
+    elif args.volume == "gyroid1024":
+        # beyond the reference's u8 coordinates: wide node words, 2^31-slot tree (8 GiB) built on the GPU
+        data = vr.Data(vr.datasets.gyroid_noise(1024))
+        what = "synthetic 1024^3 u8 gyroid shell + uniform noise (seed 42, volumerenderer_amd/datasets.py), reference camera"
     else:
         data = vr.Data(vr.datasets.bonsai_standin())
         what = "synthetic 256^3 u8 stand-in for the 256^3 CT volume the reference does not ship (seeded, volumerenderer_amd/datasets.py)"
+    wide = max(data.resulution) > 256
+    I0, IN = args.iso_begin, args.iso_count
+    if I0 < 0 or IN < 1 or I0 + IN > 256:
+        raise SystemExit("--iso-begin/--iso-count must stay inside 0..255")
     pos, forw, up = vr.main_camera(data.resulution)
 
     L = capi.lib()
     r = vr.Renderer(local_rank)
     r.upload_volume(data)
+    tb = time.perf_counter()
     build = r.build_kdt("AlwaysCenter")  # centre-split tree built on the GPU from the uploaded volume
+    build_ms = (time.perf_counter() - tb) * 1e3
     r.set_kernel(args.kernel)
     row_begin, row_end = 0, H
     if args.scaling == "strong" and args.shard == "rows":
         if args.gather:
             raise SystemExit("--gather goes with iso sharding")
-        iso_begin, iso_count = 0, 256
-        counts = [256] * world
+        iso_begin, iso_count = I0, IN
+        counts = [IN] * world
         row_begin, row_end = sharding.row_shard(rank, world, H)
     elif args.scaling == "strong":
-        iso_begin, iso_count = sharding.iso_shard(rank, world, 0, 256)
-        counts = [sharding.iso_shard(k, world, 0, 256)[1] for k in range(world)]
+        iso_begin, iso_count = sharding.iso_shard(rank, world, I0, IN)
+        counts = [sharding.iso_shard(k, world, I0, IN)[1] for k in range(world)]
     else:
-        iso_begin, iso_count = 0, 256
-        counts = [256] * world
+        iso_begin, iso_count = I0, IN
+        counts = [IN] * world
     view = vr.raytrace._view(pos, forw, up, W, H, 2.0)
     d_rgb = torch.empty((iso_count, row_end - row_begin, W, 3), dtype=torch.uint8, device="cuda")
     d_stats = torch.zeros((iso_count, 7), dtype=torch.int64, device="cuda")
@@ -246,8 +259,9 @@ def main():
             except (OSError, ValueError):
                 traffic = None
         out = {
-            "metric": "Mrays/s on the %s iso sweep (iso 0..255) at %dx%d" % (
-                {"skull": "Skull.vol", "c60": "C60.vol", "standin256": "256^3 stand-in"}[args.volume], W, H),
+            "metric": "Mrays/s on the %s iso sweep (iso %d..%d) at %dx%d" % (
+                {"skull": "Skull.vol", "c60": "C60.vol", "standin256": "256^3 stand-in",
+                 "gyroid1024": "1024^3 gyroid"}[args.volume], I0, I0 + IN - 1, W, H),
             "value": rays_per_step * args.steps / dt / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -259,7 +273,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": what,
-            "config": {"workload": "%s_%dx%d_iso0-255_sweep" % (args.volume, W, H),
+            "config": {"workload": "%s_%dx%d_iso%d-%d_sweep" % (args.volume, W, H, I0, I0 + IN - 1),
                        "volume": "%s %dx%dx%d" % ((args.volume,) + tuple(data.resulution)),
                        "tree": "SlimKDT AlwaysCenter built on the GPU, %d nodes, depth %d" % (
                            build.number_of_nodes, build.layer_count),
@@ -268,27 +282,31 @@ def main():
                            ("row-blocks" if args.shard == "rows" else "iso-blocks") if args.scaling == "strong" else
                            "one sweep per rank"),
                        "gather": bool(args.gather and world > 1),
-                       "kernel": capi.lib().vr_kernel_name(args.kernel).decode()},
+                       "kernel": "wide" if wide else capi.lib().vr_kernel_name(args.kernel).decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {0: "vr_k_sweep", 4: "vr_k_trace", 5: "vr_k_sweep"}.get(args.kernel, "vr_k_render"), "kernel_ms": kernel_ms, "launches_timed": int(launches.value),
+                         "kernel": "vr_k_render_wide" if wide else (
+                             {0: "vr_k_sweep" if IN >= 8 else "vr_k_trace", 4: "vr_k_trace", 5: "vr_k_sweep"}.get(
+                                 args.kernel, "vr_k_render")), "kernel_ms": kernel_ms, "launches_timed": int(launches.value),
                          "algorithmic_bytes_per_launch": alg_bytes, "nodes_checked_per_launch": nodes_checked,
                          "measured_copy_GBps": copy_ceiling_gbps(torch),
                          "note": ("algorithmic bytes = the reference's node reads (4 B x nodes_checked) + 3 B per pixel; the "
                                   "kernels read far fewer nodes (resume traversal; the sweep kernel also shares traversals "
                                   "between iso values), so frac prices the reference's work and can exceed 1 -- HBM itself "
                                   "moves `traffic` bytes per launch"),
-                         "counters": profile_counters() if (args.volume == "skull" and W == 1024) else None},
+                         "counters": profile_counters() if (args.volume == "skull" and W == 1024 and IN == 256) else None},
             "errors": errors,
         }
-        if args.volume != "skull" or W != 1024:
+        if args.volume != "skull" or W != 1024 or IN != 256:
             out["roofline"]["traffic"] = None  # the committed counter pass is for the default workload only
-        if not args.no_cpu_baseline and world == 1:
+        if wide:
+            out["build_ms_gpu"] = build_ms  # the host builder and the CPU oracle cannot run at this size
+        elif not args.no_cpu_baseline and world == 1:
             kdt = vr.SlimKDT.newHeursiticPartition(data, "AlwaysCenter")  # host copy for the CPU legs
-            out["cpu_baseline"] = cpu_baseline(kdt, pos, forw, up, W)
+            out["cpu_baseline"] = cpu_baseline(kdt, pos, forw, up, W, I0, IN)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
             threads = max(1, min(16, len(os.sched_getaffinity(0))))
-            out["cpu_all_cores"] = cpu_all_cores(kdt, pos, forw, up, W, threads)
+            out["cpu_all_cores"] = cpu_all_cores(kdt, pos, forw, up, W, threads, I0, IN)
         print(json.dumps(out), flush=True)
     r.close()
     if world > 1:

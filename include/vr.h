@@ -201,7 +201,8 @@ int vr_download_kdt(vr_ctx *ctx, uint32_t *nodes_out, uint64_t cap_slots, uint64
  * above 256 voxels (VR_H_ALWAYS_CENTER only, built on the GPU; 1024^3 voxels give 2^31 slots = 8 GiB).
  * vr_render / vr_render_sweep / vr_render_device then work as for any other tree, with one difference:
  * the cell/flag tap word is  x | y<<10 | z<<20 | VR_FLAG_*<<30.  A malformed wide tree cannot make the
- * kernel read outside the array: such rays end as misses and are counted in vr_render_stats.errors. */
+ * kernel read outside the array: such rays end as misses and are counted in vr_render_stats.errors.
+ * A wide tree has at most 2^31 slots (node levels 0..30). */
 int vr_upload_kdt_wide(vr_ctx *ctx, const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3]);
 
 /* Copies slots [first_slot, first_slot + n_slots) of the device-resident wide tree back (the whole

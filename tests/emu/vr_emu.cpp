@@ -185,7 +185,7 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
 
 namespace {
 struct HostPath {
-    uint32_t word[VR_MAX_DEPTH];
+    uint32_t word[VR_WIDE_MAX_DEPTH];
     uint32_t get(uint32_t d) const { return word[d]; }
     void set(uint32_t d, uint32_t w) { word[d] = w; }
 };

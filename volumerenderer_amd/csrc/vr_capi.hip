@@ -234,7 +234,7 @@ int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint
 int vr_upload_kdt_wide(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3])
 {
     if (!c || !nodes || !n_slots || !root_dim) return VR_EARG;
-    if (n_slots > ((uint64_t)1 << 32)) return VR_EARG;
+    if (n_slots > VR_WIDE_MAX_SLOTS) return VR_EARG;
     for (int a = 0; a < 3; a++)
         if (root_dim[a] == 0 || root_dim[a] >= VR_WIDE_MAX_RES) return VR_EARG;
     hipError_t e = hipSetDevice(c->device);
@@ -245,7 +245,7 @@ int vr_upload_kdt_wide(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const
     if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
     c->n_slots = n_slots;
-    c->max_depth = VR_MAX_DEPTH; /* not walked on the host: the kernel checks index, depth and axis as it goes */
+    c->max_depth = VR_WIDE_MAX_DEPTH; /* not walked on the host: the kernel checks index, depth and axis as it goes */
     for (int a = 0; a < 3; a++) c->root_dim[a] = root_dim[a];
     c->wide = true;
     return VR_OK;
@@ -261,7 +261,7 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
         /* beyond the reference's coordinate range: centre split only, built on the device in wide node words */
         if (heuristic != VR_H_ALWAYS_CENTER) return VR_EARG;
         const uint32_t depth = vr_center_tree_depth(c->res[0], c->res[1], c->res[2]);
-        if (depth >= VR_MAX_DEPTH + 1u) return VR_ETOODEEP;
+        if (depth > VR_WIDE_MAX_DEPTH) return VR_ETOODEEP;
         const uint64_t n_slots = (uint64_t)1 << (depth + 1);
         hipError_t e = hipSetDevice(c->device);
         if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }

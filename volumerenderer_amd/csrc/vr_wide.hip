@@ -1,11 +1,10 @@
 /*
  * vr_wide.hip -- render kernel for volumes beyond the reference's u8 coordinates (up to 1024 voxels per
  * axis; the reference's SPACESIZE is u8, src/typedef.zig:1).  One thread per pixel and iso value walks
- * the wide node array as uploaded or built (vr_trace_wide.h: restart with a path cache), with the
- * lane's path cache in LDS as [level][thread] words.
+ * the wide node array as uploaded or built (vr_trace_wide.h: resume after a MOVE instead of restart), with
+ * the lane's path (one word per level) in LDS as [level][thread] words.
  *
- * A wide tree is up to 2^32 four-byte words (16 GiB); node fetches use 64-bit addresses and go to HBM
- * through L2 -- nothing of it is staged in LDS, the replayed levels never leave the CU.
+ * A wide tree is up to 2^31 four-byte words (8 GiB); node fetches use 64-bit addresses.
  */
 #include "vr_internal.h"
 #include "vr_trace_wide.h"
@@ -20,7 +19,7 @@ struct WideFetch {
 };
 
 struct LdsPath {
-    uint32_t *col; /* this thread's column of the [VR_MAX_DEPTH][kWideThreads] cache */
+    uint32_t *col; /* this thread's column of the [VR_WIDE_MAX_DEPTH][kWideThreads] path store */
     __device__ __forceinline__ uint32_t get(uint32_t d) const { return col[d * kWideThreads]; }
     __device__ __forceinline__ void set(uint32_t d, uint32_t w) { col[d * kWideThreads] = w; }
 };
@@ -42,7 +41,7 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_render_wide(VrViewK v, cons
                                                                  uint8_t *__restrict__ rgb,
                                                                  vr_render_stats *__restrict__ stats, VrTapsK taps)
 {
-    __shared__ uint32_t s_path[VR_MAX_DEPTH * kWideThreads];
+    __shared__ uint32_t s_path[VR_WIDE_MAX_DEPTH * kWideThreads];
 
     const uint32_t tiles_x = (v.width + 15u) / 16u;
     const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
