@@ -158,10 +158,19 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
                              % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    # VR_BENCH_REHEARSAL=1: rehearse the N > 1 control flow on a box with ONE GPU -- every rank renders on device 0,
+    # the process group is gloo and the reductions run on host tensors.  Its numbers mean nothing (the ranks share a GPU).
+    rehearsal = os.environ.get("VR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if rehearsal else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W = H = args.width
     if args.volume == "skull":
@@ -212,7 +221,7 @@ def main():
         capi.check(L.vr_render_device(r.handle, C.byref(view), iso_begin, iso_count, row_begin, row_end, d_rgb.data_ptr(),
                                       d_stats.data_ptr(), None, C.c_void_p(stream)), "vr_render_device")
         if args.gather and world > 1:
-            sharding.gather_frames(d_rgb, counts, dst=0)
+            sharding.gather_frames(d_rgb.cpu() if rehearsal else d_rgb, counts, dst=0)
 
     def fence():
         torch.cuda.synchronize()
@@ -233,7 +242,7 @@ def main():
     tot_ms, launches = C.c_double(), C.c_uint32()
     capi.check(L.vr_timing_read(r.handle, C.byref(tot_ms), C.byref(launches)), "vr_timing_read")
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -242,7 +251,7 @@ def main():
     nodes_checked = int(stats[:, 0].sum())
     errors = int(stats[:, 6].sum())
     rays_per_step_rank = iso_count * W * (row_end - row_begin)
-    rays_total = torch.tensor([rays_per_step_rank], dtype=torch.float64, device="cuda")
+    rays_total = torch.tensor([rays_per_step_rank], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)
     rays_per_step = float(rays_total.item())
@@ -297,6 +306,8 @@ def main():
                          "counters": profile_counters() if (args.volume == "skull" and W == 1024 and IN == 256) else None},
             "errors": errors,
         }
+        if rehearsal:
+            out["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
         if args.volume != "skull" or W != 1024 or IN != 256:
             out["roofline"]["traffic"] = None  # the committed counter pass is for the default workload only
         if wide:
