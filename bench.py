@@ -294,7 +294,7 @@ def main():
                        "kernel": "wide" if wide else capi.lib().vr_kernel_name(args.kernel).decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "vr_k_render_wide" if wide else (
+                         "kernel": ("vr_k_render_wide" if args.kernel in (1, 2, 3) else "vr_k_trace_wide") if wide else (
                              {0: "vr_k_sweep" if IN >= 8 else "vr_k_trace", 4: "vr_k_trace", 5: "vr_k_sweep"}.get(
                                  args.kernel, "vr_k_render")), "kernel_ms": kernel_ms, "launches_timed": int(launches.value),
                          "algorithmic_bytes_per_launch": alg_bytes, "nodes_checked_per_launch": nodes_checked,

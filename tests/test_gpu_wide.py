@@ -16,6 +16,9 @@ from test_wide_cpu import WIDE_SHAPES, narrow_to_wide_cell_flag, narrow_to_wide_
 
 pytestmark = pytest.mark.gpu
 
+# wide trees: the pipeline (compacted ray list + persistent waves with lane refill) and the per-pixel kernel
+WIDE_KERNELS = [capi.KERNEL_DEFAULT, capi.KERNEL_RESUME]
+
 
 def _gpu(renderer, pos, forw, up, w, h, vp, iso):
     img = vr.Image(w, h)
@@ -32,12 +35,17 @@ def test_wide_kernel_on_c60_matches_reference_renders_and_u8_oracle(oracle, c60_
         out = r.renderSweep(pos, forw, up, 512, 512, 2.0, 0, 256)
         for iso in range(256):
             assert (out["rgb"][iso][:, :, 0] == golden_gray[iso]).all(), iso
+        r.set_kernel(capi.KERNEL_RESUME)
+        per_pixel = r.renderSweep(pos, forw, up, 512, 512, 2.0, 0, 256)
+        assert (per_pixel["rgb"] == out["rgb"]).all() and per_pixel["stats"] == out["stats"]
         for iso in (30, 100, 200):
             ref = oracle.render(nodes, rd, pos, forw, up, 200, 160, 2.0, iso)
             ref["cell_flag"] = narrow_to_wide_cell_flag(ref["cell_flag"])
-            got = _gpu(r, pos, forw, up, 200, 160, 2.0, iso)
-            assert_same_render(got, ref, "wide kernel on C60 iso %d" % iso)
-            assert got["stats"]["nodes_checked"] == ref["stats"].nodes_checked and got["stats"]["errors"] == 0
+            for kern in WIDE_KERNELS:
+                r.set_kernel(kern)
+                got = _gpu(r, pos, forw, up, 200, 160, 2.0, iso)
+                assert_same_render(got, ref, "wide kernel %d on C60 iso %d" % (kern, iso))
+                assert got["stats"]["nodes_checked"] == ref["stats"].nodes_checked and got["stats"]["errors"] == 0
 
 
 @pytest.mark.parametrize("shape,kind", WIDE_SHAPES + [((1024, 5, 3), "smooth"), ((400, 300, 3), "noise")])
@@ -60,12 +68,15 @@ def test_wide_volumes_gpu_build_and_render_match_wide_oracle(oracle, shape, kind
             pos, forw, up = oracle.main_camera(shape, pos)
             for vp, iso in ((0.2, 0), (3.0, 90), (0.7, 200)):
                 ref = oracle.render(nodes, rd, pos, forw, up, 70, 50, vp, iso, wide=True)
-                got = _gpu(r, pos, forw, up, 70, 50, vp, iso)
-                assert_same_render(got, ref, "%s %s iso %d" % (shape, pos, iso))
-                s = got["stats"]
-                assert (s["nodes_checked"], s["hit_count"], s["miss_count"], s["oob_count"], s["moves"], s["errors"]) == (
-                    ref["stats"].nodes_checked, ref["stats"].hit_count, ref["stats"].miss_count, ref["stats"].oob_count,
-                    ref["stats"].moves, 0)
+                for kern in WIDE_KERNELS:
+                    r.set_kernel(kern)
+                    got = _gpu(r, pos, forw, up, 70, 50, vp, iso)
+                    assert_same_render(got, ref, "%s %s iso %d kernel %d" % (shape, pos, iso, kern))
+                    s = got["stats"]
+                    assert (s["nodes_checked"], s["hit_count"], s["miss_count"], s["oob_count"], s["moves"], s["errors"]) == (
+                        ref["stats"].nodes_checked, ref["stats"].hit_count, ref["stats"].miss_count, ref["stats"].oob_count,
+                        ref["stats"].moves, 0)
+                r.set_kernel(capi.KERNEL_DEFAULT)
         # the uploaded form of the same tree renders the same
         pos, forw, up = oracle.main_camera(shape)
         a = _gpu(r, pos, forw, up, 64, 64, 1.0, 120)
@@ -110,9 +121,11 @@ def test_wide_malformed_tree_ends_every_ray(oracle):
     pos, forw, up = oracle.main_camera((301, 201, 101))
     with vr.Renderer(0) as r:
         r.upload_kdt(vr.SlimKDT(nodes, np.array([300, 200, 100]), wide=True))
-        out = r.renderSweep(pos, forw, up, 64, 64, 2.0, 100, 1)
-        s = out["stats"][0]
-        assert s["hit_count"] + s["miss_count"] + s["oob_count"] == 64 * 64
+        for kern in WIDE_KERNELS:
+            r.set_kernel(kern)
+            out = r.renderSweep(pos, forw, up, 64, 64, 2.0, 100, 1)
+            s = out["stats"][0]
+            assert s["hit_count"] + s["miss_count"] + s["oob_count"] == 64 * 64
 
 
 def test_wide_argument_checks():
@@ -184,6 +197,10 @@ def test_gyroid_1024_cubed_full_size_properties():
             stats += d_stats.cpu().numpy()[0]
         assert [int(s) for s in stats] == [ws[k] for k in ("nodes_checked", "hit_count", "miss_count", "oob_count",
                                                             "escape_help_events", "moves", "errors")]
+        r.set_kernel(capi.KERNEL_RESUME)  # the per-pixel kernel renders the same frame, counter for counter
+        other = r.renderSweep(pos, forw, up, W, H, 2.0, iso, 1)
+        assert (other["rgb"] == whole["rgb"]).all() and other["stats"][0] == ws
+        r.set_kernel(capi.KERNEL_DEFAULT)
         two = r.renderSweep(pos, forw, up, 1024, 1024, 2.0, iso, 2)
         for j in range(2):
             one = r.renderSweep(pos, forw, up, 1024, 1024, 2.0, iso + j, 1)

@@ -372,24 +372,8 @@ int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_
         taps.node = d_taps->node;
     }
     const int variant = c->variant;
-    if (c->wide) {
-        if (d_stats) VR_HIP(hipMemsetAsync(d_stats, 0, sizeof(vr_render_stats) * iso_count, s));
-        hipEvent_t w0 = nullptr, w1 = nullptr;
-        if (c->timing) {
-            while (c->ev.size() < c->ev_used + 2) {
-                hipEvent_t e;
-                VR_HIP(hipEventCreate(&e));
-                c->ev.push_back(e);
-            }
-            w0 = c->ev[c->ev_used];
-            w1 = c->ev[c->ev_used + 1];
-        }
-        VR_HIP(vr_launch_render_wide(s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
-                                     (vr_render_stats *)d_stats, taps, w0, w1));
-        if (c->timing) c->ev_used += 2;
-        return VR_OK;
-    }
-    if (variant == VR_KERNEL_DEFAULT || variant == VR_KERNEL_PIPELINE || variant == VR_KERNEL_SWEEP) {
+    const bool per_pixel = variant == VR_KERNEL_RESTART_GLOBAL || variant == VR_KERNEL_RESTART_LDS || variant == VR_KERNEL_RESUME;
+    if (!per_pixel) {
         /* growing the scratch is the only allocation on this path; it happens when a larger view comes */
         const size_t need = vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count);
         if (need > c->work_cap) VR_HIP(hipStreamSynchronize(s));
@@ -407,8 +391,12 @@ int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_
         ev0 = c->ev[c->ev_used];
         ev1 = c->ev[c->ev_used + 1];
     }
-    VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
-                            row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, c->d_work, c->n_cus, ev0, ev1));
+    if (c->wide)
+        VR_HIP(vr_launch_render_wide(variant, s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
+                                     (vr_render_stats *)d_stats, taps, c->d_work, c->n_cus, ev0, ev1));
+    else
+        VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
+                                row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, c->d_work, c->n_cus, ev0, ev1));
     if (c->timing) c->ev_used += 2;
     return VR_OK;
 }

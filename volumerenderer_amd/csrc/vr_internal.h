@@ -46,10 +46,12 @@ hipError_t vr_launch_build_center(hipStream_t stream, const uint8_t *d_vox, uint
                                   uint32_t depth, uint32_t *d_raw, uint32_t *d_prepared);
 
 
-/* Volumes beyond 256 voxels per axis (vr_wide.hip): one thread per pixel and iso value on the wide node array.
+/* Volumes beyond 256 voxels per axis, on the wide node array: the pipeline with the wide lane code, or the
+ * per-pixel kernel when `variant` names one.  `workspace` as for vr_launch_render.
  * vr_launch_build_center with d_prepared = nullptr builds that array (wide node words) instead. */
-hipError_t vr_launch_render_wide(hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes, uint32_t iso_begin,
-                                 uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
-                                 vr_render_stats *d_stats, const VrTapsK &taps, hipEvent_t ev_begin, hipEvent_t ev_end);
+hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes,
+                                 uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
+                                 vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
+                                 hipEvent_t ev_begin, hipEvent_t ev_end);
 
 #endif

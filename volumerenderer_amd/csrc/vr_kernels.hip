@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "vr_internal.h"
+#include "vr_trace_wide.h"
 
 namespace {
 
@@ -309,10 +310,10 @@ __global__ void vr_k_oob_stats(vr_render_stats *__restrict__ stats, uint32_t iso
     if (k < iso_count) stats[k].oob_count = frame_pixels - *n_active;
 }
 
-__global__ void vr_k_tap_defaults(VrTapsK taps, uint64_t n)
+__global__ void vr_k_tap_defaults(VrTapsK taps, uint64_t n, uint32_t oob_word)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (taps.cell_flag) taps.cell_flag[i] = VR_FLAG_OOB << 24;
+        if (taps.cell_flag) taps.cell_flag[i] = oob_word;
         if (taps.t) taps.t[i] = 0.0f;
         if (taps.checked) taps.checked[i] = 0u;
         if (taps.node) taps.node[i] = 0u;
@@ -812,6 +813,242 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     }
 }
 
+
+/* ------------------------------------------------------------------ wide volumes ---- */
+
+/* Volumes beyond the reference's u8 coordinates (up to 1024 voxels per axis; SPACESIZE is u8 in the reference,
+ * src/typedef.zig:1): the kernels below walk the wide node array as uploaded or built (lane code in
+ * vr_trace_wide.h), with the lane's path -- one word per level -- in LDS as [level][thread] words.  A wide tree
+ * is up to 2^31 four-byte words (8 GiB); node fetches use 64-bit addresses. */
+struct WideFetch {
+    const uint32_t *nodes;
+    __device__ __forceinline__ uint32_t operator()(uint32_t idx) const { return nodes[idx]; }
+};
+
+template <uint32_t STRIDE>
+struct LdsPath {
+    uint32_t *col; /* this thread's column of the [VR_WIDE_MAX_DEPTH][STRIDE] path store */
+    __device__ __forceinline__ uint32_t get(uint32_t d) const { return col[d * STRIDE]; }
+    __device__ __forceinline__ void set(uint32_t d, uint32_t w) { col[d * STRIDE] = w; }
+};
+
+/* one thread per pixel and iso value: a 16 x 16 pixel block, each wave an 8 x 8 tile */
+__global__ __launch_bounds__(256) void vr_k_render_wide(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t iso_begin,
+                                                        uint32_t row_begin, uint32_t n_rows, uint8_t *__restrict__ rgb,
+                                                        vr_render_stats *__restrict__ stats, VrTapsK taps)
+{
+    __shared__ uint32_t s_path[VR_WIDE_MAX_DEPTH * 256u];
+
+    const uint32_t tiles_x = (v.width + kBlockW - 1) / kBlockW;
+    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t xi = bx * kBlockW + (wave & 1u) * kTileW + (lane & 7u);
+    const uint32_t yr = by * kBlockH + (wave >> 1) * kTileH + (lane >> 3); /* row relative to row_begin */
+    const uint32_t iso = iso_begin + blockIdx.y;
+    const bool valid = xi < v.width && yr < n_rows;
+
+    VrHit h;
+    h.t = 0.0f; h.flag = VR_FLAG_OOB; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
+    if (valid) {
+        const VrRay ray = vr_make_ray(v, xi, yr + row_begin);
+        LdsPath<256u> path{ s_path + threadIdx.x };
+        h = vr_trace_wide(v, ray, iso, WideFetch{ nodes }, path);
+        const uint64_t pix = ((uint64_t)blockIdx.y * n_rows + yr) * v.width + xi;
+        const uint8_t g = h.flag == VR_FLAG_HIT ? vr_shade(h.t) : (uint8_t)0;
+        rgb[pix * 3 + 0] = g;
+        rgb[pix * 3 + 1] = g;
+        rgb[pix * 3 + 2] = g;
+        if (taps.cell_flag) taps.cell_flag[pix] = h.cell | (h.flag << VR_WIDE_FLAG_SHIFT);
+        if (taps.t) taps.t[pix] = h.flag == VR_FLAG_OOB ? 0.0f : h.t;
+        if (taps.checked) taps.checked[pix] = h.checked;
+        if (taps.node) taps.node[pix] = h.node;
+    }
+
+    if (stats) {
+        const uint32_t c_checked = wave_sum(valid ? h.checked : 0u);
+        const uint32_t c_hit = wave_sum(valid && h.flag == VR_FLAG_HIT ? 1u : 0u);
+        const uint32_t c_miss = wave_sum(valid && h.flag == VR_FLAG_MISS ? 1u : 0u);
+        const uint32_t c_oob = wave_sum(valid && h.flag == VR_FLAG_OOB ? 1u : 0u);
+        const uint32_t c_esc = wave_sum(valid ? h.escapes : 0u);
+        const uint32_t c_moves = wave_sum(valid ? h.moves : 0u);
+        const uint32_t c_err = wave_sum(valid ? h.error : 0u);
+        if (lane == 0) {
+            vr_render_stats *s = stats + blockIdx.y;
+            add_stat(&s->nodes_checked, c_checked);
+            add_stat(&s->hit_count, c_hit);
+            add_stat(&s->miss_count, c_miss);
+            add_stat(&s->oob_count, c_oob);
+            add_stat(&s->escape_help_events, c_esc);
+            add_stat(&s->moves, c_moves);
+            add_stat(&s->errors, c_err);
+        }
+    }
+}
+
+#ifndef VR_WIDE_DESCEND_TRIPS
+#define VR_WIDE_DESCEND_TRIPS 6
+#endif
+/* The persistent kernel of the pipeline for wide trees: the compacted ray list, one queue head per iso value,
+ * waves that refill idle lanes (as vr_k_trace), the wide lane code.  A round is a bounded descend followed, for
+ * the lanes whose node excluded the iso value, by the MOVE and the pop (LDS only).  Dynamic LDS: the path store. */
+template <bool TAPS>
+__global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace_wide(
+    VrViewK v, const uint32_t *__restrict__ nodes, const float4 *__restrict__ ray_dt, const uint32_t *__restrict__ ray_pix,
+    const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ heads, uint32_t iso_begin, uint32_t iso_count,
+    uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats, VrTapsK taps)
+{
+    extern __shared__ uint32_t s_dyn[];
+    LdsPath<kTraceThreads> path{ s_dyn + threadIdx.x };
+    const WideFetch fetch{ nodes };
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_active = *n_active_ptr;
+    const uint32_t waves_per_block = kTraceThreads / 64u;
+    const uint32_t n_waves = gridDim.x * waves_per_block, gw = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const uint32_t k0 = (uint32_t)(((uint64_t)gw * iso_count) / n_waves);
+
+    for (uint32_t visit = 0; visit < iso_count; visit++) {
+        uint32_t k = k0 + visit;
+        if (k >= iso_count) k -= iso_count;
+        const uint32_t iso = iso_begin + k;
+        uint8_t *frame = rgb + (uint64_t)k * frame_pixels * 3u;
+        const uint64_t tap_base = (uint64_t)k * frame_pixels;
+
+        VrWideLane L;
+        uint32_t pix = 0;
+        bool alive = false, exhausted = false;
+        unsigned long long a_checked = 0;
+        uint32_t a_hit = 0, a_miss = 0, a_moves = 0, a_esc = 0, a_err = 0;
+
+        for (;;) {
+            const unsigned long long idle = __ballot(!alive);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (!exhausted && n_idle >= kRefillMin) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&heads[k], n_idle);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!alive && mine < n_active) {
+                    const float4 r = ray_dt[mine];
+                    pix = ray_pix[mine];
+                    vr_wide_begin(L, v, r.x, r.y, r.z, r.w);
+                    alive = true;
+                }
+                exhausted = base + n_idle >= n_active;
+            }
+            if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
+
+            if (alive) {
+                const uint32_t go = vr_wide_descend(L, v, iso, fetch, path, VR_WIDE_DESCEND_TRIPS);
+                if (go == VR_GO_HIT) { /* shade and store (src/raytrace.zig:56-61) */
+                    const uint8_t g = vr_shade(L.t);
+                    frame[(uint64_t)pix * 3u + 0u] = g;
+                    frame[(uint64_t)pix * 3u + 1u] = g;
+                    frame[(uint64_t)pix * 3u + 2u] = g;
+                    a_hit++;
+                    alive = false;
+                    if (TAPS) {
+                        if (taps.cell_flag) taps.cell_flag[tap_base + pix] = L.c | (VR_FLAG_HIT << VR_WIDE_FLAG_SHIFT);
+                        if (taps.node) taps.node[tap_base + pix] = L.idx;
+                    }
+                } else if (go != VR_GO_MORE) {
+                    bool on = false;
+                    if (go == VR_GO_EXCLUDED && L.checked <= VR_MAX_CHECKED) {
+                        a_moves++;
+                        on = vr_wide_move(L, v, path, a_esc);
+                    } else {
+                        a_err++;
+                    }
+                    if (!on) { /* left the volume: a miss, the pixel stays black (src/raytrace.zig:66-68) */
+                        a_miss++;
+                        alive = false;
+                        if (TAPS) {
+                            if (taps.cell_flag) taps.cell_flag[tap_base + pix] = VR_FLAG_MISS << VR_WIDE_FLAG_SHIFT;
+                            if (taps.node) taps.node[tap_base + pix] = 0u;
+                        }
+                    }
+                }
+                if (!alive) {
+                    a_checked += L.checked;
+                    if (TAPS) {
+                        if (taps.t) taps.t[tap_base + pix] = L.t;
+                        if (taps.checked) taps.checked[tap_base + pix] = L.checked;
+                    }
+                }
+            }
+        }
+
+        if (stats) {
+            const unsigned long long c_checked = wave_sum64(a_checked);
+            const uint32_t c_hit = wave_sum(a_hit), c_miss = wave_sum(a_miss), c_moves = wave_sum(a_moves);
+            const uint32_t c_esc = wave_sum(a_esc), c_err = wave_sum(a_err);
+            if (lane == 0) {
+                vr_render_stats *s = stats + k;
+                add_stat(&s->nodes_checked, c_checked);
+                add_stat(&s->hit_count, c_hit);
+                add_stat(&s->miss_count, c_miss);
+                add_stat(&s->escape_help_events, c_esc);
+                add_stat(&s->moves, c_moves);
+                add_stat(&s->errors, c_err);
+            }
+        }
+    }
+}
+
+/* workspace layout of the pipeline and its pre-pass (entry test once per call, dense ray list in tile order) */
+struct Prepass {
+    float4 *ray_dt;
+    uint32_t *ray_pix, *n_active, *heads;
+};
+
+hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_count, uint32_t row_begin, uint32_t n_rows,
+                          uint32_t center_out, uint8_t *d_rgb, vr_render_stats *d_stats, const VrTapsK &taps,
+                          uint32_t oob_word, void *workspace, Prepass &pp)
+{
+    const size_t n_pix = (size_t)view.width * n_rows;
+    const uint32_t n_tiles = padded_tiles(view.width, n_rows);
+    char *w = (char *)workspace;
+    pp.ray_dt = (float4 *)w;
+    w += (n_pix * sizeof(float4) + 255) & ~(size_t)255;
+    pp.ray_pix = (uint32_t *)w;
+    w += (n_pix * sizeof(uint32_t) + 255) & ~(size_t)255;
+    uint32_t *tile_cnt = (uint32_t *)w;
+    w += ((size_t)n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255;
+    pp.n_active = (uint32_t *)w;
+    w += 256;
+    pp.heads = (uint32_t *)w;
+
+    hipError_t e;
+    const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
+    if ((e = hipMemsetAsync(pp.heads, 0, (size_t)iso_count * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
+    const uint32_t tile_blocks = (n_tiles + 3u) / 4u;
+    hipLaunchKernelGGL(vr_k_count, dim3(tile_blocks), dim3(256), 0, stream, view, row_begin, n_rows, n_tiles, center_out, tile_cnt);
+    hipLaunchKernelGGL(vr_k_scan, dim3(1), dim3(1024), 0, stream, tile_cnt, n_tiles, pp.n_active);
+    hipLaunchKernelGGL(vr_k_compact, dim3(tile_blocks), dim3(256), 0, stream, view, row_begin, n_rows, n_tiles, center_out, tile_cnt,
+                       pp.ray_dt, pp.ray_pix);
+    if (d_stats)
+        hipLaunchKernelGGL(vr_k_oob_stats, dim3((iso_count + 255u) / 256u), dim3(256), 0, stream, d_stats, iso_count,
+                           (uint64_t)n_pix, pp.n_active);
+    if (any_tap)
+        hipLaunchKernelGGL(vr_k_tap_defaults, dim3(2048), dim3(256), 0, stream, taps, (uint64_t)n_pix * iso_count, oob_word);
+    return hipGetLastError();
+}
+
+/* the dynamic-LDS ceiling is a property of the function on the current device: raised once per device and kernel */
+hipError_t allow_full_lds(const void *fn, int fn_id)
+{
+    static bool lds_set[64][6];
+    int dev = 0;
+    hipError_t e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !lds_set[dev][fn_id]) {
+        if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u))) != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) lds_set[dev][fn_id] = true;
+    }
+    return hipSuccess;
+}
+
 } // namespace
 
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count)
@@ -870,35 +1107,16 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
 
     /* ---- pipeline ---- */
     const size_t n_pix = (size_t)view.width * n_rows;
-    const uint32_t n_tiles = padded_tiles(view.width, n_rows);
-    char *w = (char *)workspace;
-    float4 *ray_dt = (float4 *)w;
-    w += (n_pix * sizeof(float4) + 255) & ~(size_t)255;
-    uint32_t *ray_pix = (uint32_t *)w;
-    w += (n_pix * sizeof(uint32_t) + 255) & ~(size_t)255;
-    uint32_t *tile_cnt = (uint32_t *)w;
-    w += ((size_t)n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255;
-    uint32_t *n_active = (uint32_t *)w;
-    w += 256;
-    uint32_t *heads = (uint32_t *)w;
-
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
     /* a block of iso values: the sweep kernel, which shares traversals between iso values (for fewer than 8 the
      * kernel with one traversal per iso value is as fast or a little faster) */
     const bool sweep = variant == VR_KERNEL_SWEEP || (use_default && iso_count >= 8u);
-    const uint32_t center_out = sweep ? 1u : 0u;
-    if ((e = hipMemsetAsync(heads, 0, (size_t)iso_count * sizeof(uint32_t), stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
-    const uint32_t tile_blocks = (n_tiles + 3u) / 4u;
-    hipLaunchKernelGGL(vr_k_count, dim3(tile_blocks), dim3(256), 0, stream, view, row_begin, n_rows, n_tiles, center_out, tile_cnt);
-    hipLaunchKernelGGL(vr_k_scan, dim3(1), dim3(1024), 0, stream, tile_cnt, n_tiles, n_active);
-    hipLaunchKernelGGL(vr_k_compact, dim3(tile_blocks), dim3(256), 0, stream, view, row_begin, n_rows, n_tiles, center_out, tile_cnt,
-                       ray_dt, ray_pix);
-    if (d_stats)
-        hipLaunchKernelGGL(vr_k_oob_stats, dim3((iso_count + 255u) / 256u), dim3(256), 0, stream, d_stats, iso_count,
-                           (uint64_t)n_pix, n_active);
-    if (any_tap) hipLaunchKernelGGL(vr_k_tap_defaults, dim3(2048), dim3(256), 0, stream, taps, (uint64_t)n_pix * iso_count);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    Prepass pp;
+    if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
+                            VR_FLAG_OOB << 24, workspace, pp)) != hipSuccess)
+        return e;
+    float4 *ray_dt = pp.ray_dt;
+    uint32_t *ray_pix = pp.ray_pix, *n_active = pp.n_active, *heads = pp.heads;
 
     /* persistent grid: kTraceBlocksPerCu blocks per CU.  A block's LDS holds the path stacks and, in what is
      * left of its share of the CU's 160 KiB, the top K levels of the tree (two thirds of all node reads).
@@ -918,14 +1136,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     const int fn_id = (sweep ? 2 : 0) + (any_tap ? 1 : 0);
     const void *fn = sweep ? (any_tap ? (const void *)vr_k_sweep<true> : (const void *)vr_k_sweep<false>)
                            : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
-    /* the attribute is a property of the function on the current device: set once per device and kernel */
-    static bool lds_set[64][4];
-    int dev = 0;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !lds_set[dev][fn_id]) {
-        if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u))) != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) lds_set[dev][fn_id] = true;
-    }
+    if ((e = allow_full_lds(fn, fn_id)) != hipSuccess) return e;
     const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
     const uint64_t frame_pixels = n_pix;
     const uint32_t stack_rows = stack_levels + 1u;
@@ -983,4 +1194,42 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     }
 #endif
     return hipSuccess;
+}
+
+/* Wide trees: the pipeline (pre-pass + vr_k_trace_wide) by default, the per-pixel kernel for the variants that
+ * name a per-pixel kernel (a cross-check with no ray list, no queues and no lane refill). */
+hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes,
+                                 uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
+                                 vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
+                                 hipEvent_t ev_begin, hipEvent_t ev_end)
+{
+    const uint32_t n_rows = row_end - row_begin;
+    hipError_t e = hipSuccess;
+    if (variant == VR_KERNEL_RESTART_GLOBAL || variant == VR_KERNEL_RESTART_LDS || variant == VR_KERNEL_RESUME) {
+        const uint32_t tiles = ((view.width + kBlockW - 1) / kBlockW) * ((n_rows + kBlockH - 1) / kBlockH);
+        if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(vr_k_render_wide, dim3(tiles, iso_count), dim3(256), 0, stream, view, d_nodes, iso_begin, row_begin,
+                           n_rows, d_rgb, d_stats, taps);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (ev_end) e = hipEventRecord(ev_end, stream);
+        return e;
+    }
+    Prepass pp;
+    if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, 0u, d_rgb, d_stats, taps,
+                            VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp)) != hipSuccess)
+        return e;
+    const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
+    const void *fn = any_tap ? (const void *)vr_k_trace_wide<true> : (const void *)vr_k_trace_wide<false>;
+    if ((e = allow_full_lds(fn, 4 + (any_tap ? 1 : 0))) != hipSuccess) return e;
+    const size_t lds = (size_t)VR_WIDE_MAX_DEPTH * kTraceThreads * sizeof(uint32_t);
+    const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
+    const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
+    void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&pp.ray_dt, (void *)&pp.ray_pix, (void *)&pp.n_active,
+                     (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels, (void *)&d_rgb,
+                     (void *)&d_stats, (void *)&taps };
+    if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
+    if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, lds, stream)) != hipSuccess) return e;
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (ev_end) e = hipEventRecord(ev_end, stream);
+    return e;
 }

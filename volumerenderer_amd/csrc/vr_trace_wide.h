@@ -46,105 +46,138 @@
  * (hi on side 0, lo on side 1) the split replaced */
 VR_HD uint32_t vr_wide_field(uint32_t packed, uint32_t sh) { return (packed >> sh) & 0x3ffu; }
 
+#define VR_GO_ERROR 3u /* malformed tree: index, depth, axis or partition out of range */
+
+/* One ray in flight.  (idx, d) is the node the walk stands on, [lo, hi) its box, c the cell of the point at t. */
+struct VrWideLane {
+    float dx, dy, dz, t;
+    uint32_t lo, hi, c, idx, d;
+    uint32_t checked; /* reference-defined node checks so far */
+};
+
+/* the ray enters at t (inside the root box): SpaceTracker.new, src/SlimKDT.zig:55-64 */
+VR_HD void vr_wide_begin(VrWideLane &L, const VrViewK &v, float dx, float dy, float dz, float t)
+{
+    L.dx = dx; L.dy = dy; L.dz = dz; L.t = t;
+    L.lo = 0; L.hi = vr_pack10(v.rdx, v.rdy, v.rdz);
+    L.idx = 0; L.d = 0; L.checked = 0;
+    const float px = v.ox + dx * t, py = v.oy + dy * t, pz = v.oz + dz * t;
+    L.c = vr_pack10((uint32_t)px, (uint32_t)py, (uint32_t)pz);
+}
+
+/* Volume.splitGlobal (src/geo.zig:256-275) on the side of the cell; returns the path word of the level */
+VR_HD uint32_t vr_wide_split(VrWideLane &L, uint32_t part, uint32_t axis, uint32_t sh)
+{
+    const uint32_t side = vr_wide_field(L.c, sh) < part ? 0u : 1u;
+    const uint32_t bound = side ? L.lo : L.hi;
+    const uint32_t old = vr_wide_field(bound, sh);
+    const uint32_t nb = side ? (old > part ? old : part) : (old < part ? old : part);
+    const uint32_t moved = bound ^ ((old ^ nb) << sh);
+    L.lo = side ? moved : L.lo;
+    L.hi = side ? L.hi : moved;
+    L.idx = 2u * L.idx + 1u + side;
+    return part | (axis << 10) | (sh << 12) | (side << 17) | (old << 18);
+}
+
+/* SpaceTracker.zoom (src/SlimKDT.zig:90-103) for at most max_trips levels: until a node excludes the iso value
+ * (VR_GO_EXCLUDED, MOVE next), a leaf holds it (VR_GO_HIT, src/raytrace.zig:178-187) or the budget is used up
+ * (VR_GO_MORE) */
+template <class NodeFetch, class Path>
+VR_HD uint32_t vr_wide_descend(VrWideLane &L, const VrViewK &v, uint32_t iso, const NodeFetch &fetch, Path &path,
+                               uint32_t max_trips)
+{
+    for (uint32_t trip = 0; trip < max_trips; trip++) {
+        if (L.idx >= v.n_slots) return VR_GO_ERROR;
+        const uint32_t n = fetch(L.idx);
+        L.checked++;
+        const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
+        if (!(mn <= iso && iso <= mx)) return VR_GO_EXCLUDED;
+        if (L.hi - L.lo == VR_F_ONES) return VR_GO_HIT;
+        const uint32_t axis = VR_WIDE_AXIS(n), part = VR_WIDE_PART(n);
+        if (axis > 2u || part >= VR_WIDE_MAX_RES || L.d >= VR_WIDE_MAX_DEPTH) return VR_GO_ERROR;
+        path.set(L.d, vr_wide_split(L, part, axis, axis * 10u));
+        L.d++;
+    }
+    return VR_GO_MORE;
+}
+
+/* MOVE (src/raytrace.zig:199-246) out of the box of the excluded node, then the reference's restart at the root
+ * folded into a step to the other child of the lowest ancestor that holds the new point.  Returns false when
+ * the point has left the root box (the ray is a miss). */
+template <class Path>
+VR_HD bool vr_wide_move(VrWideLane &L, const VrViewK &v, Path &path, uint32_t &escapes)
+{
+    uint32_t lo = L.lo, hi = L.hi;
+    const float lx = (float)(lo & 0x3ffu), ly = (float)((lo >> 10) & 0x3ffu), lz = (float)(lo >> 20);
+    const float hx = (float)(hi & 0x3ffu), hy = (float)((hi >> 10) & 0x3ffu), hz = (float)(hi >> 20);
+    float t = INFINITY;
+    t = fminf(t, vr_plane_t(L.dx >= 0.0f ? hx : lx, v.ox, L.dx));
+    t = fminf(t, vr_plane_t(L.dy >= 0.0f ? hy : ly, v.oy, L.dy));
+    t = fminf(t, vr_plane_t(L.dz >= 0.0f ? hz : lz, v.oz, L.dz));
+    t += 0.0001f;
+    float px, py, pz, i = 0.0f;
+    for (;;) { /* escape help, :233-242 */
+        px = v.ox + L.dx * t; py = v.oy + L.dy * t; pz = v.oz + L.dz * t;
+        if (!(lx <= px && px < hx && ly <= py && py < hy && lz <= pz && pz < hz)) break;
+        t += 0.001f * i;
+        i += 1.0f;
+        escapes++;
+    }
+    L.t = t;
+    /* the reference resets to the root here; its loop condition (:161) is the root box test */
+    if (!vr_root_contains(v, px, py, pz)) return false;
+    const uint32_t c = vr_pack10((uint32_t)px, (uint32_t)py, (uint32_t)pz);
+    L.c = c;
+    /* undo splits until the box holds the new cell (for a point inside the root box, lo <= cell < hi on the
+     * integer cell is Range.containsFloat on the point) */
+    uint32_t in3 = 0;
+    for (uint32_t a = 0; a < 3u; a++) {
+        const uint32_t ca = vr_wide_field(c, a * 10u);
+        in3 |= (vr_wide_field(lo, a * 10u) <= ca && ca < vr_wide_field(hi, a * 10u) ? 1u : 0u) << a;
+    }
+    uint32_t k = L.d, e = 0;
+    while (in3 != 7u && k > 0u) {
+        k--;
+        e = path.get(k);
+        const uint32_t axis = (e >> 10) & 3u, sh = (e >> 12) & 31u, old = (e >> 18) & 0x3ffu;
+        const uint32_t keep = ~(0x3ffu << sh), put = old << sh;
+        if (e & (1u << 17)) lo = (lo & keep) | put;
+        else hi = (hi & keep) | put;
+        const uint32_t ca = vr_wide_field(c, sh);
+        const uint32_t ok = vr_wide_field(lo, sh) <= ca && ca < vr_wide_field(hi, sh) ? 1u : 0u;
+        in3 = (in3 & ~(1u << axis)) | (ok << axis);
+    }
+    L.lo = lo; L.hi = hi;
+    if (k < L.d) {
+        /* the node at level k passed its test before and holds the new point: the reference's walk from the
+         * root checks levels 0..k again and takes the child on the point's side */
+        L.checked += k + 1u;
+        L.idx = ((L.idx + 1u) >> (L.d - k)) - 1u;
+        path.set(k, vr_wide_split(L, e & 0x3ffu, (e >> 10) & 3u, (e >> 12) & 31u));
+        L.d = k + 1u;
+    }
+    return true;
+}
+
+/* one whole ray */
 template <class NodeFetch, class Path>
 VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Path &path)
 {
     VrHit h;
     h.t = 0.0f; h.flag = 2u; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
     if (ray.oob) return h;
-    float t = ray.t;
-    uint32_t lo = 0, hi = vr_pack10(v.rdx, v.rdy, v.rdz); /* box of the node at (idx, d) */
-    uint32_t idx = 0, d = 0;
-    float px = v.ox + ray.dx * t, py = v.oy + ray.dy * t, pz = v.oz + ray.dz * t; /* inside the root box: not oob */
-    uint32_t c = vr_pack10((uint32_t)px, (uint32_t)py, (uint32_t)pz);
-    for (;;) {
-        /* SpaceTracker.zoom (src/SlimKDT.zig:90-103) until a node excludes the iso value or a leaf holds it */
-        for (;;) {
-            if (idx >= v.n_slots) { h.error = 1; break; }
-            const uint32_t n = fetch(idx);
-            h.checked++;
-            const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
-            if (!(mn <= iso && iso <= mx)) break;
-            if (hi - lo == VR_F_ONES) { /* box size 1, src/raytrace.zig:178-187 */
-                h.t = t; h.flag = 1u; h.node = idx; h.cell = c;
-                return h;
-            }
-            const uint32_t axis = VR_WIDE_AXIS(n), part = VR_WIDE_PART(n);
-            if (axis > 2u || part >= VR_WIDE_MAX_RES || d >= VR_WIDE_MAX_DEPTH) { h.error = 1; break; }
-            const uint32_t sh = axis * 10u;
-            const uint32_t side = vr_wide_field(c, sh) < part ? 0u : 1u;
-            const uint32_t bound = side ? lo : hi; /* Volume.splitGlobal, src/geo.zig:256-275 */
-            const uint32_t old = vr_wide_field(bound, sh);
-            const uint32_t nb = side ? (old > part ? old : part) : (old < part ? old : part);
-            const uint32_t moved = bound ^ ((old ^ nb) << sh);
-            lo = side ? moved : lo;
-            hi = side ? hi : moved;
-            path.set(d, part | (axis << 10) | (sh << 12) | (side << 17) | (old << 18));
-            idx = 2u * idx + 1u + side;
-            d++;
-        }
-        if (h.error) break;
-        /* MOVE: leave the node box through the nearest exit plane, :199-205 */
-        const float lx = (float)(lo & 0x3ffu), ly = (float)((lo >> 10) & 0x3ffu), lz = (float)(lo >> 20);
-        const float hx = (float)(hi & 0x3ffu), hy = (float)((hi >> 10) & 0x3ffu), hz = (float)(hi >> 20);
-        t = INFINITY;
-        t = fminf(t, vr_plane_t(ray.dx >= 0.0f ? hx : lx, v.ox, ray.dx));
-        t = fminf(t, vr_plane_t(ray.dy >= 0.0f ? hy : ly, v.oy, ray.dy));
-        t = fminf(t, vr_plane_t(ray.dz >= 0.0f ? hz : lz, v.oz, ray.dz));
-        t += 0.0001f;
-        if (++h.moves > VR_MAX_MOVES) { h.error = 1; break; }
-        float i = 0.0f;
-        for (;;) { /* escape help, :233-242 */
-            px = v.ox + ray.dx * t; py = v.oy + ray.dy * t; pz = v.oz + ray.dz * t;
-            if (!(lx <= px && px < hx && ly <= py && py < hy && lz <= pz && pz < hz)) break;
-            t += 0.001f * i;
-            i += 1.0f;
-            h.escapes++;
-        }
-        /* the reference resets to the root here; its loop condition (:161) is the root box test */
-        if (!vr_root_contains(v, px, py, pz)) break;
-        c = vr_pack10((uint32_t)px, (uint32_t)py, (uint32_t)pz);
-        /* undo splits until the box holds the new cell (for a point inside the root box, lo <= cell < hi on the
-         * integer cell is Range.containsFloat on the point) */
-        uint32_t in3 = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (uint32_t a = 0; a < 3u; a++) {
-            const uint32_t ca = vr_wide_field(c, a * 10u);
-            in3 |= (vr_wide_field(lo, a * 10u) <= ca && ca < vr_wide_field(hi, a * 10u) ? 1u : 0u) << a;
-        }
-        uint32_t k = d, e = 0;
-        while (in3 != 7u && k > 0u) {
-            k--;
-            e = path.get(k);
-            const uint32_t axis = (e >> 10) & 3u, sh = (e >> 12) & 31u, old = (e >> 18) & 0x3ffu;
-            const uint32_t keep = ~(0x3ffu << sh), put = old << sh;
-            if (e & (1u << 17)) lo = (lo & keep) | put;
-            else hi = (hi & keep) | put;
-            const uint32_t ca = vr_wide_field(c, sh);
-            const uint32_t ok = vr_wide_field(lo, sh) <= ca && ca < vr_wide_field(hi, sh) ? 1u : 0u;
-            in3 = (in3 & ~(1u << axis)) | (ok << axis);
-        }
-        if (k < d) {
-            /* the node at level k passed its test before and holds the new point: the reference's walk from the
-             * root checks levels 0..k again and takes the child on the point's side */
-            h.checked += k + 1u;
-            const uint32_t part = e & 0x3ffu, axis = (e >> 10) & 3u, sh = (e >> 12) & 31u;
-            const uint32_t side = vr_wide_field(c, sh) < part ? 0u : 1u;
-            const uint32_t bound = side ? lo : hi;
-            const uint32_t old = vr_wide_field(bound, sh);
-            const uint32_t nb = side ? (old > part ? old : part) : (old < part ? old : part);
-            const uint32_t moved = bound ^ ((old ^ nb) << sh);
-            lo = side ? moved : lo;
-            hi = side ? hi : moved;
-            path.set(k, part | (axis << 10) | (sh << 12) | (side << 17) | (old << 18));
-            idx = 2u * (((idx + 1u) >> (d - k)) - 1u) + 1u + side;
-            d = k + 1u;
-        }
-    }
-    h.t = t;
+    VrWideLane L;
+    vr_wide_begin(L, v, ray.dx, ray.dy, ray.dz, ray.t);
     h.flag = 0u;
+    for (;;) {
+        const uint32_t go = vr_wide_descend(L, v, iso, fetch, path, 64u);
+        if (go == VR_GO_HIT) { h.flag = 1u; h.node = L.idx; h.cell = L.c; break; }
+        if (go != VR_GO_EXCLUDED || L.checked > VR_MAX_CHECKED) { h.error = 1; break; }
+        h.moves++;
+        if (!vr_wide_move(L, v, path, h.escapes)) break;
+    }
+    h.t = L.t;
+    h.checked = L.checked;
     return h;
 }
 
