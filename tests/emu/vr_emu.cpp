@@ -78,7 +78,11 @@ extern "C" int vr_emu_render(int variant, const uint32_t *nodes, uint64_t n_slot
 /* vr_div (reciprocal + two FMA corrections) against the IEEE divide on the operand range of the MOVE step:
  * numerator = plane offset (0..255) - camera coordinate, denominator = a component of a unit direction with
  * |d| >= 1e-8.  Returns the number of operand pairs whose results differ in any bit. */
-extern "C" uint64_t vr_emu_div_check(uint64_t samples, uint64_t seed)
+static uint64_t div_check(uint64_t samples, uint64_t seed, uint32_t n_offsets);
+extern "C" uint64_t vr_emu_div_check(uint64_t samples, uint64_t seed) { return div_check(samples, seed, 256u); }
+/* the same with plane offsets 0..1023: volumes of up to 1024 voxels per axis */
+extern "C" uint64_t vr_emu_div_check_wide(uint64_t samples, uint64_t seed) { return div_check(samples, seed, 1024u); }
+static uint64_t div_check(uint64_t samples, uint64_t seed, uint32_t n_offsets)
 {
     uint64_t s = seed ? seed : 88172645463325252ull, bad = 0;
     auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
@@ -92,10 +96,10 @@ extern "C" uint64_t vr_emu_div_check(uint64_t samples, uint64_t seed)
         if (!(fabsf(d) >= 1e-8f) || fabsf(d) > 1.0f) continue;
         float o;
         const uint32_t om = (uint32_t)(rnd() % 3u);
-        if (om == 0) o = (urand() * 2.0f - 1.0f) * 1000.0f;
+        if (om == 0) o = (urand() * 2.0f - 1.0f) * (n_offsets > 256u ? 3000.0f : 1000.0f);
         else if (om == 1) o = (float)((int)(rnd() % 2001u) - 1000) * 0.5f;
         else o = (urand() * 2.0f - 1.0f) * 300.0f;
-        const float n = (float)(rnd() % 256u) - o;
+        const float n = (float)(rnd() % n_offsets) - o;
         const float q = n / d, m = vr_div(n, d, 1.0f / d);
         if (std::memcmp(&q, &m, 4) != 0 && !(q == 0.0f && m == 0.0f)) bad++;
     }

@@ -9,3 +9,10 @@ def test_vr_div_equals_ieee_divide(emu_lib):
     emu_lib.vr_emu_div_check.restype = C.c_uint64
     emu_lib.vr_emu_div_check.argtypes = [C.c_uint64, C.c_uint64]
     assert emu_lib.vr_emu_div_check(100_000_000, 12345) == 0
+
+
+def test_vr_div_equals_ieee_divide_on_wide_volumes(emu_lib):
+    """Plane offsets 0..1023 (volumes of up to 1024 voxels per axis), camera coordinates up to 3000 away."""
+    emu_lib.vr_emu_div_check_wide.restype = C.c_uint64
+    emu_lib.vr_emu_div_check_wide.argtypes = [C.c_uint64, C.c_uint64]
+    assert emu_lib.vr_emu_div_check_wide(100_000_000, 999) == 0

@@ -51,6 +51,7 @@ VR_HD uint32_t vr_wide_field(uint32_t packed, uint32_t sh) { return (packed >> s
 /* One ray in flight.  (idx, d) is the node the walk stands on, [lo, hi) its box, c the cell of the point at t. */
 struct VrWideLane {
     float dx, dy, dz, t;
+    float rx, ry, rz; /* 1 / d per axis, correctly rounded; NaN where |d| < 1e-8 (see vr_plane_t_r) */
     uint32_t lo, hi, c, idx, d;
     uint32_t checked; /* reference-defined node checks so far */
 };
@@ -59,6 +60,9 @@ struct VrWideLane {
 VR_HD void vr_wide_begin(VrWideLane &L, const VrViewK &v, float dx, float dy, float dz, float t)
 {
     L.dx = dx; L.dy = dy; L.dz = dz; L.t = t;
+    L.rx = fabsf(dx) < 1e-8f ? NAN : 1.0f / dx;
+    L.ry = fabsf(dy) < 1e-8f ? NAN : 1.0f / dy;
+    L.rz = fabsf(dz) < 1e-8f ? NAN : 1.0f / dz;
     L.lo = 0; L.hi = vr_pack10(v.rdx, v.rdy, v.rdz);
     L.idx = 0; L.d = 0; L.checked = 0;
     const float px = v.ox + dx * t, py = v.oy + dy * t, pz = v.oz + dz * t;
@@ -87,7 +91,7 @@ VR_HD uint32_t vr_wide_descend(VrWideLane &L, const VrViewK &v, uint32_t iso, co
                                uint32_t max_trips)
 {
     for (uint32_t trip = 0; trip < max_trips; trip++) {
-        if (L.idx >= v.n_slots) return VR_GO_ERROR;
+        if (L.idx >= (uint32_t)v.n_slots) return VR_GO_ERROR; /* n_slots <= 2^31 */
         const uint32_t n = fetch(L.idx);
         L.checked++;
         const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
@@ -110,10 +114,11 @@ VR_HD bool vr_wide_move(VrWideLane &L, const VrViewK &v, Path &path, uint32_t &e
     uint32_t lo = L.lo, hi = L.hi;
     const float lx = (float)(lo & 0x3ffu), ly = (float)((lo >> 10) & 0x3ffu), lz = (float)(lo >> 20);
     const float hx = (float)(hi & 0x3ffu), hy = (float)((hi >> 10) & 0x3ffu), hz = (float)(hi >> 20);
-    float t = INFINITY;
-    t = fminf(t, vr_plane_t(L.dx >= 0.0f ? hx : lx, v.ox, L.dx));
-    t = fminf(t, vr_plane_t(L.dy >= 0.0f ? hy : ly, v.oy, L.dy));
-    t = fminf(t, vr_plane_t(L.dz >= 0.0f ? hz : lz, v.oz, L.dz));
+    /* the three divisions by a per-ray reciprocal with FMA corrections (vr_div: bit-identical to the IEEE
+     * divide); an axis the ray is parallel to gives NaN, which drops out of the minimum as INFINITY would */
+    float t = vr_plane_t_r(L.dx >= 0.0f ? hx : lx, v.ox, L.dx, L.rx);
+    t = fminf(t, vr_plane_t_r(L.dy >= 0.0f ? hy : ly, v.oy, L.dy, L.ry));
+    t = fminf(t, vr_plane_t_r(L.dz >= 0.0f ? hz : lz, v.oz, L.dz, L.rz));
     t += 0.0001f;
     float px, py, pz, i = 0.0f;
     for (;;) { /* escape help, :233-242 */
