@@ -46,6 +46,7 @@ pub extern fn vr_upload_volume(ctx: ?*Ctx, vox: [*]const u8, rx: u32, ry: u32, r
 pub extern fn vr_build_kdt(ctx: ?*Ctx, heuristic: c_int, stats_out: ?*BuildStats) c_int;
 pub extern fn vr_download_kdt(ctx: ?*Ctx, nodes_out: ?[*]u32, capacity: u64, n_slots_out: *u64, root_dim_out: *[3]u8) c_int;
 // volumes beyond SPACESIZE = u8 (no counterpart in the reference): wide node words, u16 root_dim
+pub extern fn vr_host_check_kdt_wide(nodes: [*]const u32, n_slots: u64, root_dim: *const [3]u16, max_depth_out: ?*u32, n_nodes_out: ?*u64) c_int;
 pub extern fn vr_upload_kdt_wide(ctx: ?*Ctx, nodes: [*]const u32, n_slots: u64, root_dim: *const [3]u16) c_int;
 pub extern fn vr_download_kdt_wide(ctx: ?*Ctx, nodes_out: ?[*]u32, first_slot: u64, n_slots: u64, n_slots_out: ?*u64, root_dim_out: ?*[3]u16) c_int;
 pub extern fn vr_save_kdt(path: [*:0]const u8, nodes: [*]const u32, n_slots: u64, root_dim: *const [3]u8) c_int;

@@ -145,6 +145,13 @@ int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t r
                         uint32_t *prepared_out, uint64_t prepared_words, uint32_t *max_depth_out,
                         uint64_t *n_nodes_out);
 
+/* The validating walk of vr_host_prepare_kdt for a tree in wide node words (volumes beyond the reference's
+ * u8 coordinates, see vr_upload_kdt_wide): VR_ETREE unless every reachable node lies inside the array and every
+ * inner node splits strictly inside its box.  No flattened copy is made; the kernels walk wide trees as they
+ * are.  max_depth_out = deepest level (root = 0; at most 30 with n_slots <= 2^31). */
+int vr_host_check_kdt_wide(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3],
+                           uint32_t *max_depth_out, uint64_t *n_nodes_out);
+
 /* Camera of the reference driver (src/main.zig:31-43): forw = norm(f32(res/2) - pos),
  * up = (forw x (0,1,0)) x forw (not normalised). */
 void vr_main_camera(const uint32_t res[3], const float pos[3], float forw_out[3], float up_out[3]);
@@ -200,9 +207,9 @@ int vr_download_kdt(vr_ctx *ctx, uint32_t *nodes_out, uint64_t cap_slots, uint64
  * A context holds a wide tree after vr_upload_kdt_wide, or after vr_build_kdt on a volume with an axis
  * above 256 voxels (VR_H_ALWAYS_CENTER only, built on the GPU; 1024^3 voxels give 2^31 slots = 8 GiB).
  * vr_render / vr_render_sweep / vr_render_device then work as for any other tree, with one difference:
- * the cell/flag tap word is  x | y<<10 | z<<20 | VR_FLAG_*<<30.  A malformed wide tree cannot make the
- * kernel read outside the array: such rays end as misses and are counted in vr_render_stats.errors.
- * A wide tree has at most 2^31 slots (node levels 0..30). */
+ * the cell/flag tap word is  x | y<<10 | z<<20 | VR_FLAG_*<<30.  vr_upload_kdt_wide validates the array with
+ * vr_host_check_kdt_wide first (VR_ETREE for a tree the reference's zoom could not traverse either), which is
+ * what lets the kernels walk it without per-node checks.  A wide tree has at most 2^31 slots (levels 0..30). */
 int vr_upload_kdt_wide(vr_ctx *ctx, const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3]);
 
 /* Copies slots [first_slot, first_slot + n_slots) of the device-resident wide tree back (the whole

@@ -118,6 +118,9 @@ int main(int argc, char **argv)
                     }
                 std::vector<uint32_t> wide(n_slots);
                 for (uint64_t i = 0; i < n_slots; i++) wide[i] = (nodes[i] & 0x00ffffffu) | (((nodes[i] >> 24) & 3u) << 28);
+                const uint16_t rdw[3] = { rd8[0], rd8[1], rd8[2] };
+                uint32_t wdepth = 0; uint64_t wcount = 0;
+                CHECK(vr_host_check_kdt_wide(wide.data(), n_slots, rdw, &wdepth, &wcount) == VR_OK && wcount == st.number_of_nodes);
                 for (uint32_t y = 0; y < h; y++)
                     for (uint32_t x = 0; x < w; x++) {
                         const VrRay ray = vr_make_ray(vraw, x, y);
@@ -134,15 +137,15 @@ int main(int argc, char **argv)
                 const uint64_t cut = 1 + rnd() % n_slots;
                 const int v = vr_host_prepare_kdt(bad.data(), cut, rd8, prep.data(), vr_prepared_words(cut), &depth, &n_nodes);
                 CHECK(v == VR_OK || v == VR_ETREE || v == VR_ETOODEEP);
-                /* the wide lane code checks as it goes: it must come back from any array of words */
+                /* the same for wide node words; the literal loop checks as it goes and must come back from any words */
                 std::vector<uint32_t> junk(cut);
                 for (auto &q : junk) q = rnd() * 2246822519u;
+                const uint16_t rd16[3] = { rd8[0], rd8[1], rd8[2] };
+                const int vw = vr_host_check_kdt_wide(junk.data(), cut, rd16, &depth, &n_nodes);
+                CHECK(vw == VR_OK || vw == VR_ETREE);
                 const VrViewK vj = make_view(rd, cams[0], res, 8, 8, 1.0f, cut);
-                for (uint32_t p = 0; p < 64; p++) {
-                    Path path;
-                    (void)vr_trace_wide(vj, vr_make_ray(vj, p & 7u, p >> 3), rnd() % 256, Fetch{ junk.data() }, path);
+                for (uint32_t p = 0; p < 64; p++)
                     (void)vr_trace_restart(vj, vr_make_ray(vj, p & 7u, p >> 3), rnd() % 256, Fetch{ junk.data() });
-                }
             }
             vr_free(nodes);
         }

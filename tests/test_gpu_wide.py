@@ -115,17 +115,13 @@ def test_wide_sweep_and_row_shards(oracle):
         assert total == sum(s["nodes_checked"] for s in out["stats"])
 
 
-def test_wide_malformed_tree_ends_every_ray(oracle):
+def test_wide_malformed_tree_is_refused_at_upload():
     rng = np.random.default_rng(5)
     nodes = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
-    pos, forw, up = oracle.main_camera((301, 201, 101))
     with vr.Renderer(0) as r:
-        r.upload_kdt(vr.SlimKDT(nodes, np.array([300, 200, 100]), wide=True))
-        for kern in WIDE_KERNELS:
-            r.set_kernel(kern)
-            out = r.renderSweep(pos, forw, up, 64, 64, 2.0, 100, 1)
-            s = out["stats"][0]
-            assert s["hit_count"] + s["miss_count"] + s["oob_count"] == 64 * 64
+        with pytest.raises(capi.VrError) as e:
+            r.upload_kdt(vr.SlimKDT(nodes, np.array([300, 200, 100]), wide=True))
+        assert e.value.code == capi.VR_ETREE
 
 
 def test_wide_argument_checks():
@@ -141,6 +137,7 @@ def test_wide_argument_checks():
         assert L.vr_download_kdt(r.handle, None, 0, C.byref(n), None) == capi.VR_ESTATE  # wide tree: other call
         rd = (C.c_uint16 * 3)(1024, 4, 4)
         one = np.ones(8, np.uint32)
+        assert L.vr_upload_kdt_wide(r.handle, one.ctypes.data, 2 ** 31 + 1, rd) == capi.VR_EARG
         assert L.vr_upload_kdt_wide(r.handle, one.ctypes.data, 8, rd) == capi.VR_EARG
 
 

@@ -81,11 +81,30 @@ def test_wide_lane_code_on_c60_equals_u8_oracle(oracle, emu_lib, c60_vox, c60_tr
         assert_same_render(got, ref, "wide lane code on C60 iso %d" % iso)
 
 
-def test_wide_lane_code_survives_malformed_trees(oracle, emu_lib):
-    """Random words as a tree: every ray must end (error flagged or not) without leaving the array."""
+def check_wide(nodes, rd):
+    import ctypes as C
+    from volumerenderer_amd import capi
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+    depth, count = C.c_uint32(), C.c_uint64()
+    rc = capi.lib().vr_host_check_kdt_wide(nodes.ctypes.data, len(nodes), (C.c_uint16 * 3)(*[int(x) for x in rd]),
+                                           C.byref(depth), C.byref(count))
+    return rc, depth.value, count.value
+
+
+def test_wide_tree_validation(oracle):
+    """The kernels walk wide trees without per-node checks; the validating walk in front of the upload must
+    accept what the builder produces and refuse everything a descent could leave the array or loop on."""
+    from volumerenderer_amd import capi
     rng = np.random.default_rng(5)
-    nodes = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
-    rd = np.array([300, 200, 100], np.uint16)
-    pos, forw, up = oracle.main_camera((301, 201, 101))
-    got = emu_wide(emu_lib, nodes, rd, pos, forw, up, 32, 32, 2.0, 100)
-    assert int(got["sums"][1] + got["sums"][2] + got["sums"][3]) == 32 * 32
+    vox = random_volume(rng, (300, 9, 7), "noise")
+    nodes, rd, st = oracle.build_kdt(vox, wide=True)
+    rc, depth, count = check_wide(nodes, rd)
+    assert (rc, depth, count) == (0, st.layer_count, st.number_of_nodes)
+    assert check_wide(nodes[:1000], rd)[0] == capi.VR_ETREE                      # children beyond the array
+    bad = nodes.copy(); bad[0] = (bad[0] & 0x0000ffff) | (299 << 16)             # partition on the box face
+    assert check_wide(bad, rd)[0] == capi.VR_ETREE
+    bad = nodes.copy(); bad[5] |= 3 << 28                                        # axis 3
+    assert check_wide(bad, rd)[0] == capi.VR_ETREE
+    junk = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
+    assert check_wide(junk, [300, 200, 100])[0] == capi.VR_ETREE
+    assert check_wide(nodes, [1024, 8, 6])[0] == capi.VR_EARG

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for pass in "$@"; do
   i=$((i+1))
-  timeout -s KILL 200 rocprofv3 --pmc $pass --output-format csv -d $R/$out/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/p$i.json 2> $R/$out/p$i.err || { echo "pass $i failed"; tail -3 $R/$out/p$i.err; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc $pass --output-format csv -d $R/$out/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline $VR_PMC_BENCH_ARGS > $R/$out/p$i.json 2> $R/$out/p$i.err || { echo "pass $i failed"; tail -3 $R/$out/p$i.err; exit 1; }
 done
 python3 - <<PY
 import csv,glob,collections

@@ -35,7 +35,7 @@ HEURISTICS = {
 
 # every symbol include/vr.h declares; tests check that the library exports each of them
 EXPORTS = [
-    "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_alloc_host", "vr_free_host", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
+    "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_host_check_kdt_wide", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_alloc_host", "vr_free_host", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
     "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_upload_kdt_wide", "vr_download_kdt_wide", "vr_render",
     "vr_render_sweep", "vr_render_device", "vr_sync", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
@@ -93,6 +93,7 @@ def lib():
     L.vr_host_build_kdt.argtypes = [vp, u32p, C.c_int, C.c_uint64, C.POINTER(u32p), C.POINTER(C.c_uint64), u8p,
                                     C.POINTER(BuildStats)]
     L.vr_host_prepare_kdt.argtypes = [vp, C.c_uint64, u8p, vp, C.c_uint64, u32p, C.POINTER(C.c_uint64)]
+    L.vr_host_check_kdt_wide.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint16), u32p, C.POINTER(C.c_uint64)]
     L.vr_prepared_words.argtypes = [C.c_uint64]
     L.vr_prepared_words.restype = C.c_uint64
     L.vr_main_camera.argtypes = [u32p, f32p, f32p, f32p]

@@ -237,6 +237,10 @@ int vr_upload_kdt_wide(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const
     if (n_slots > VR_WIDE_MAX_SLOTS) return VR_EARG;
     for (int a = 0; a < 3; a++)
         if (root_dim[a] == 0 || root_dim[a] >= VR_WIDE_MAX_RES) return VR_EARG;
+    /* validate on the host before anything reaches the device: the kernels walk the array without checks */
+    uint32_t max_depth = 0;
+    const int rc = vr_host_check_kdt_wide(nodes, n_slots, root_dim, &max_depth, nullptr);
+    if (rc != VR_OK) return rc;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
     free_prepared(c);
@@ -245,7 +249,7 @@ int vr_upload_kdt_wide(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const
     if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
     c->n_slots = n_slots;
-    c->max_depth = VR_WIDE_MAX_DEPTH; /* not walked on the host: the kernel checks index, depth and axis as it goes */
+    c->max_depth = max_depth;
     for (int a = 0; a < 3; a++) c->root_dim[a] = root_dim[a];
     c->wide = true;
     return VR_OK;

@@ -424,6 +424,47 @@ int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t r
     return VR_OK;
 }
 
+int vr_host_check_kdt_wide(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3], uint32_t *max_depth_out,
+                           uint64_t *n_nodes_out)
+{
+    if (!nodes || !n_slots || !root_dim) return VR_EARG;
+    if (n_slots > ((uint64_t)1 << 31)) return VR_EARG;
+    for (int a = 0; a < 3; a++)
+        if (root_dim[a] == 0 || root_dim[a] > 1023) return VR_EARG;
+    struct Item { uint64_t idx; uint16_t lo[3], hi[3]; uint32_t depth; };
+    std::vector<Item> todo;
+    todo.reserve(128);
+    Item root;
+    root.idx = 0; root.depth = 0;
+    for (int a = 0; a < 3; a++) { root.lo[a] = 0; root.hi[a] = root_dim[a]; }
+    todo.push_back(root);
+    uint32_t max_depth = 0;
+    uint64_t count = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.idx >= n_slots) return VR_ETREE; /* a descent would read past the array */
+        const uint32_t n = nodes[it.idx];
+        const uint32_t axis = (n >> 28) & 3u, part = (n >> 16) & 0xfffu;
+        count++;
+        if (it.depth > max_depth) max_depth = it.depth;
+        const uint32_t size = (uint32_t)(it.hi[0] - it.lo[0]) * (uint32_t)(it.hi[1] - it.lo[1]) * (uint32_t)(it.hi[2] - it.lo[2]);
+        if (size == 1) continue; /* leaf cell: src/raytrace.zig:178 */
+        /* an inner node must split strictly inside its box (see vr_host_prepare_kdt) */
+        if (axis > 2u || part <= it.lo[axis] || part >= it.hi[axis]) return VR_ETREE;
+        Item l = it, r = it;
+        l.idx = 2 * it.idx + 1; r.idx = 2 * it.idx + 2;
+        l.depth = r.depth = it.depth + 1;
+        l.hi[axis] = (uint16_t)part;
+        r.lo[axis] = (uint16_t)part;
+        todo.push_back(r);
+        todo.push_back(l);
+    }
+    if (max_depth_out) *max_depth_out = max_depth;
+    if (n_nodes_out) *n_nodes_out = count;
+    return VR_OK;
+}
+
 void vr_free(void *p) { std::free(p); }
 
 } // extern "C"

@@ -817,8 +817,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
 /* ------------------------------------------------------------------ wide volumes ---- */
 
 /* Volumes beyond the reference's u8 coordinates (up to 1024 voxels per axis; SPACESIZE is u8 in the reference,
- * src/typedef.zig:1): the kernels below walk the wide node array as uploaded or built (lane code in
- * vr_trace_wide.h), with the lane's path -- one word per level -- in LDS as [level][thread] words.  A wide tree
+ * src/typedef.zig:1): the kernels below walk the wide node array as built, or as uploaded and validated (lane
+ * code in vr_trace_wide.h), with the lane's path -- one word per level -- in LDS as [level][thread] words.  A wide tree
  * is up to 2^31 four-byte words (8 GiB); node fetches use 64-bit addresses. */
 struct WideFetch {
     const uint32_t *nodes;
@@ -888,24 +888,37 @@ __global__ __launch_bounds__(256) void vr_k_render_wide(VrViewK v, const uint32_
 #ifndef VR_WIDE_DESCEND_TRIPS
 #define VR_WIDE_DESCEND_TRIPS 6
 #endif
+#ifndef VR_WIDE_THREADS
+#define VR_WIDE_THREADS 1024
+#endif
+#ifndef VR_WIDE_BLOCKS_PER_CU
+#define VR_WIDE_BLOCKS_PER_CU 1
+#endif
+/* block shape of the wide persistent kernel: the path store costs 120 B of LDS per lane, so a CU holds at most
+ * 1365 lanes (21 waves) of it */
+constexpr uint32_t kWideThreads = VR_WIDE_THREADS, kWideBlocksPerCu = VR_WIDE_BLOCKS_PER_CU;
 /* The persistent kernel of the pipeline for wide trees: the compacted ray list, one queue head per iso value,
  * waves that refill idle lanes (as vr_k_trace), the wide lane code.  A round is a bounded descend followed, for
  * the lanes whose node excluded the iso value, by the MOVE and the pop (LDS only).  Dynamic LDS: the path store. */
 template <bool TAPS>
-__global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace_wide(
+__global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
     VrViewK v, const uint32_t *__restrict__ nodes, const float4 *__restrict__ ray_dt, const uint32_t *__restrict__ ray_pix,
     const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ heads, uint32_t iso_begin, uint32_t iso_count,
     uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats, VrTapsK taps)
 {
     extern __shared__ uint32_t s_dyn[];
-    LdsPath<kTraceThreads> path{ s_dyn + threadIdx.x };
+    LdsPath<kWideThreads> path{ s_dyn + threadIdx.x };
     const WideFetch fetch{ nodes };
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_active = *n_active_ptr;
-    const uint32_t waves_per_block = kTraceThreads / 64u;
+    const uint32_t waves_per_block = kWideThreads / 64u;
     const uint32_t n_waves = gridDim.x * waves_per_block, gw = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const uint32_t k0 = (uint32_t)(((uint64_t)gw * iso_count) / n_waves);
+#ifdef VR_DIAG
+    unsigned long long d_acc[20] = { 0 };
+    DIAG_T(d_begin);
+#endif
 
     for (uint32_t visit = 0; visit < iso_count; visit++) {
         uint32_t k = k0 + visit;
@@ -921,6 +934,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace_
         uint32_t a_hit = 0, a_miss = 0, a_moves = 0, a_esc = 0, a_err = 0;
 
         for (;;) {
+            DIAG_T(d_t0);
             const unsigned long long idle = __ballot(!alive);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (!exhausted && n_idle >= kRefillMin) {
@@ -937,9 +951,19 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace_
                 exhausted = base + n_idle >= n_active;
             }
             if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
+            DIAG_T(d_t1);
+            DIAG_ADD(0, d_t1 - d_t0);
+            DIAG_ADD(5, 1);
+            DIAG_ADD(10, __popcll(__ballot(alive)));
+#ifdef VR_DIAG
+            uint32_t d_go = VR_GO_MORE;
+#endif
 
             if (alive) {
                 const uint32_t go = vr_wide_descend(L, v, iso, fetch, path, VR_WIDE_DESCEND_TRIPS);
+#ifdef VR_DIAG
+                d_go = go;
+#endif
                 if (go == VR_GO_HIT) { /* shade and store (src/raytrace.zig:56-61) */
                     const uint8_t g = vr_shade(L.t);
                     frame[(uint64_t)pix * 3u + 0u] = g;
@@ -951,12 +975,12 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace_
                         if (taps.cell_flag) taps.cell_flag[tap_base + pix] = L.c | (VR_FLAG_HIT << VR_WIDE_FLAG_SHIFT);
                         if (taps.node) taps.node[tap_base + pix] = L.idx;
                     }
-                } else if (go != VR_GO_MORE) {
+                } else if (go == VR_GO_EXCLUDED) {
                     bool on = false;
-                    if (go == VR_GO_EXCLUDED && L.checked <= VR_MAX_CHECKED) {
+                    if (L.checked <= VR_MAX_CHECKED) {
                         a_moves++;
                         on = vr_wide_move(L, v, path, a_esc);
-                    } else {
+                    } else { /* safety valve, never reached on a valid tree */
                         a_err++;
                     }
                     if (!on) { /* left the volume: a miss, the pixel stays black (src/raytrace.zig:66-68) */
@@ -976,6 +1000,15 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace_
                     }
                 }
             }
+#ifdef VR_DIAG
+            {
+                DIAG_T(d_t3);
+                DIAG_ADD(1, d_t3 - d_t1);
+                DIAG_ADD(3, wave_sum(d_go == VR_GO_EXCLUDED ? 1u : 0u));
+                DIAG_ADD(4, wave_sum(d_go == VR_GO_HIT ? 1u : 0u));
+                DIAG_ADD(2, wave_sum(d_go == VR_GO_MORE ? 1u : 0u));
+            }
+#endif
         }
 
         if (stats) {
@@ -993,6 +1026,15 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace_
             }
         }
     }
+#ifdef VR_DIAG
+    {
+        DIAG_T(d_end);
+        d_acc[11] = d_end - d_begin;
+        d_acc[16] = 1;
+        if (lane == 0)
+            for (int i = 0; i < 20; i++) atomicAdd(&g_diag[i], d_acc[i]);
+    }
+#endif
 }
 
 /* workspace layout of the pipeline and its pre-pass (entry test once per call, dense ray list in tile order) */
@@ -1221,15 +1263,29 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
     const void *fn = any_tap ? (const void *)vr_k_trace_wide<true> : (const void *)vr_k_trace_wide<false>;
     if ((e = allow_full_lds(fn, 4 + (any_tap ? 1 : 0))) != hipSuccess) return e;
-    const size_t lds = (size_t)VR_WIDE_MAX_DEPTH * kTraceThreads * sizeof(uint32_t);
-    const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
+    const size_t lds = (size_t)VR_WIDE_MAX_DEPTH * kWideThreads * sizeof(uint32_t);
+    const uint32_t blocks = (uint32_t)n_cus * kWideBlocksPerCu;
     const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
     void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&pp.ray_dt, (void *)&pp.ray_pix, (void *)&pp.n_active,
                      (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels, (void *)&d_rgb,
                      (void *)&d_stats, (void *)&taps };
     if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
-    if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, lds, stream)) != hipSuccess) return e;
+    if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kWideThreads), args, lds, stream)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_end) e = hipEventRecord(ev_end, stream);
+#ifdef VR_DIAG
+    {
+        unsigned long long h[20], z[20] = { 0 };
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z);
+        const double w = (double)h[16], it = (double)h[5];
+        fprintf(stderr,
+                "[diag wide] waves %.0f  cycles/wave %.0f  rounds/wave %.0f\n"
+                "[diag wide] per round: refill %.0f cyc, rest %.0f cyc; alive lanes %.1f; lanes ending the round in: "
+                "descend unfinished %.1f, excluded (MOVE) %.1f, hit %.2f\n",
+                w, h[11] / w, it / w, h[0] / it, h[1] / it, h[10] / it, h[2] / it, h[3] / it, h[4] / it);
+    }
+#endif
     return e;
 }

@@ -21,9 +21,11 @@
  * Hit cell, t, flags and the reference-defined check count are those of the literal loop; only nodes
  * below the ancestor are read.  Boxes are two words of three 10-bit fields (x | y<<10 | z<<20).
  *
- * Unlike the flattened array of the u8 kernels, wide trees are walked as uploaded, so the loop keeps
- * index, depth, axis and partition checks (a malformed tree ends the ray with error = 1 instead of
- * reading outside the array).  Heap indices stay below 2^31: levels 0..30.
+ * Wide trees are walked as uploaded or built, without a flattened copy and without per-node checks: the
+ * GPU builder produces valid trees by construction and uploaded ones pass the validating walk
+ * vr_host_check_kdt_wide first (every reachable node inside the array, every inner node splitting strictly
+ * inside its box -- so a box of size 1 is exactly a leaf and a split replaces a bound by the partition).
+ * Heap indices stay below 2^31: levels 0..30.
  *
  * `Path` is the lane's per-level store: get(d) / set(d, word) for levels 0..VR_WIDE_MAX_DEPTH-1.
  */
@@ -46,8 +48,6 @@
  * (hi on side 0, lo on side 1) the split replaced */
 VR_HD uint32_t vr_wide_field(uint32_t packed, uint32_t sh) { return (packed >> sh) & 0x3ffu; }
 
-#define VR_GO_ERROR 3u /* malformed tree: index, depth, axis or partition out of range */
-
 /* One ray in flight.  (idx, d) is the node the walk stands on, [lo, hi) its box, c the cell of the point at t. */
 struct VrWideLane {
     float dx, dy, dz, t;
@@ -69,14 +69,14 @@ VR_HD void vr_wide_begin(VrWideLane &L, const VrViewK &v, float dx, float dy, fl
     L.c = vr_pack10((uint32_t)px, (uint32_t)py, (uint32_t)pz);
 }
 
-/* Volume.splitGlobal (src/geo.zig:256-275) on the side of the cell; returns the path word of the level */
+/* Volume.splitGlobal (src/geo.zig:256-275) on the side of the cell; returns the path word of the level.  The
+ * partition lies strictly inside the box (validated tree), so the min / max of the reference is the partition. */
 VR_HD uint32_t vr_wide_split(VrWideLane &L, uint32_t part, uint32_t axis, uint32_t sh)
 {
     const uint32_t side = vr_wide_field(L.c, sh) < part ? 0u : 1u;
     const uint32_t bound = side ? L.lo : L.hi;
     const uint32_t old = vr_wide_field(bound, sh);
-    const uint32_t nb = side ? (old > part ? old : part) : (old < part ? old : part);
-    const uint32_t moved = bound ^ ((old ^ nb) << sh);
+    const uint32_t moved = bound ^ ((old ^ part) << sh);
     L.lo = side ? moved : L.lo;
     L.hi = side ? L.hi : moved;
     L.idx = 2u * L.idx + 1u + side;
@@ -91,14 +91,12 @@ VR_HD uint32_t vr_wide_descend(VrWideLane &L, const VrViewK &v, uint32_t iso, co
                                uint32_t max_trips)
 {
     for (uint32_t trip = 0; trip < max_trips; trip++) {
-        if (L.idx >= (uint32_t)v.n_slots) return VR_GO_ERROR; /* n_slots <= 2^31 */
         const uint32_t n = fetch(L.idx);
         L.checked++;
         const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
         if (!(mn <= iso && iso <= mx)) return VR_GO_EXCLUDED;
         if (L.hi - L.lo == VR_F_ONES) return VR_GO_HIT;
         const uint32_t axis = VR_WIDE_AXIS(n), part = VR_WIDE_PART(n);
-        if (axis > 2u || part >= VR_WIDE_MAX_RES || L.d >= VR_WIDE_MAX_DEPTH) return VR_GO_ERROR;
         path.set(L.d, vr_wide_split(L, part, axis, axis * 10u));
         L.d++;
     }
@@ -175,9 +173,9 @@ VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, Node
     vr_wide_begin(L, v, ray.dx, ray.dy, ray.dz, ray.t);
     h.flag = 0u;
     for (;;) {
-        const uint32_t go = vr_wide_descend(L, v, iso, fetch, path, 64u);
+        const uint32_t go = vr_wide_descend(L, v, iso, fetch, path, VR_WIDE_MAX_DEPTH + 1u);
         if (go == VR_GO_HIT) { h.flag = 1u; h.node = L.idx; h.cell = L.c; break; }
-        if (go != VR_GO_EXCLUDED || L.checked > VR_MAX_CHECKED) { h.error = 1; break; }
+        if (L.checked > VR_MAX_CHECKED) { h.error = 1; break; } /* safety valve, never reached on a valid tree */
         h.moves++;
         if (!vr_wide_move(L, v, path, h.escapes)) break;
     }
