@@ -197,8 +197,8 @@ struct HostPath {
 
 extern "C" int vr_emu_wide(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3], const float src[3],
                            const float forw[3], const float up[3], uint32_t width, uint32_t height,
-                           float viewport_width, uint32_t iso, uint8_t *rgb, uint32_t *cell_flag, float *t_out,
-                           uint32_t *checked, uint32_t *node, uint64_t *sums /*7*/)
+                           float viewport_width, uint32_t iso, uint32_t pop_trips, uint8_t *rgb, uint32_t *cell_flag,
+                           float *t_out, uint32_t *checked, uint32_t *node, uint64_t *sums /*7*/)
 {
     VrViewK k;
     k.ox = src[0]; k.oy = src[1]; k.oz = src[2];
@@ -219,7 +219,7 @@ extern "C" int vr_emu_wide(const uint32_t *nodes, uint64_t n_slots, const uint16
         for (uint32_t xi = 0; xi < width; xi++) {
             VrRay ray = vr_make_ray(k, xi, yi);
             HostPath path;
-            VrHit h = vr_trace_wide(k, ray, iso, HostFetch{ nodes }, path);
+            VrHit h = vr_trace_wide(k, ray, iso, HostFetch{ nodes }, path, pop_trips ? pop_trips : 64u);
             uint64_t pix = (uint64_t)yi * width + xi;
             uint8_t g = h.flag == 1u ? vr_shade(h.t) : 0;
             rgb[pix * 3] = rgb[pix * 3 + 1] = rgb[pix * 3 + 2] = g;

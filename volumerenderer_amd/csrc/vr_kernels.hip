@@ -888,6 +888,9 @@ __global__ __launch_bounds__(256) void vr_k_render_wide(VrViewK v, const uint32_
 #ifndef VR_WIDE_DESCEND_TRIPS
 #define VR_WIDE_DESCEND_TRIPS 6
 #endif
+#ifndef VR_WIDE_POP_TRIPS
+#define VR_WIDE_POP_TRIPS 64 /* levels a lane may pop per round; bounds of 3..8 measured no faster than none */
+#endif
 #ifndef VR_WIDE_THREADS
 #define VR_WIDE_THREADS 1024
 #endif
@@ -898,8 +901,9 @@ __global__ __launch_bounds__(256) void vr_k_render_wide(VrViewK v, const uint32_
  * 1365 lanes (21 waves) of it */
 constexpr uint32_t kWideThreads = VR_WIDE_THREADS, kWideBlocksPerCu = VR_WIDE_BLOCKS_PER_CU;
 /* The persistent kernel of the pipeline for wide trees: the compacted ray list, one queue head per iso value,
- * waves that refill idle lanes (as vr_k_trace), the wide lane code.  A round is a bounded descend followed, for
- * the lanes whose node excluded the iso value, by the MOVE and the pop (LDS only).  Dynamic LDS: the path store. */
+ * waves that refill idle lanes (as vr_k_trace), the wide lane code.  A round is a bounded descend, the MOVE for the
+ * lanes whose node excluded the iso value, and a bounded pop (LDS only); a lane that runs out of a budget carries
+ * on in the next round, so the wave does not run at the length of its slowest lane.  Dynamic LDS: the path store. */
 template <bool TAPS>
 __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
     VrViewK v, const uint32_t *__restrict__ nodes, const float4 *__restrict__ ray_dt, const uint32_t *__restrict__ ray_pix,
@@ -929,7 +933,7 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
 
         VrWideLane L;
         uint32_t pix = 0;
-        bool alive = false, exhausted = false;
+        bool alive = false, exhausted = false, popping = false;
         unsigned long long a_checked = 0;
         uint32_t a_hit = 0, a_miss = 0, a_moves = 0, a_esc = 0, a_err = 0;
 
@@ -947,6 +951,7 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
                     pix = ray_pix[mine];
                     vr_wide_begin(L, v, r.x, r.y, r.z, r.w);
                     alive = true;
+                    popping = false;
                 }
                 exhausted = base + n_idle >= n_active;
             }
@@ -960,7 +965,8 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
 #endif
 
             if (alive) {
-                const uint32_t go = vr_wide_descend(L, v, iso, fetch, path, VR_WIDE_DESCEND_TRIPS);
+                uint32_t go = VR_GO_MORE;
+                if (!popping) go = vr_wide_descend(L, v, iso, fetch, path, VR_WIDE_DESCEND_TRIPS);
 #ifdef VR_DIAG
                 d_go = go;
 #endif
@@ -979,7 +985,8 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
                     bool on = false;
                     if (L.checked <= VR_MAX_CHECKED) {
                         a_moves++;
-                        on = vr_wide_move(L, v, path, a_esc);
+                        on = vr_wide_move(L, v, a_esc);
+                        popping = on;
                     } else { /* safety valve, never reached on a valid tree */
                         a_err++;
                     }
@@ -992,6 +999,8 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
                         }
                     }
                 }
+                /* pop to the lowest ancestor that holds the new point (bounded: the rest next round) */
+                if (alive && popping) popping = !vr_wide_pop(L, path, VR_WIDE_POP_TRIPS);
                 if (!alive) {
                     a_checked += L.checked;
                     if (TAPS) {

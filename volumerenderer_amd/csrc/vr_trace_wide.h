@@ -54,6 +54,7 @@ struct VrWideLane {
     float rx, ry, rz; /* 1 / d per axis, correctly rounded; NaN where |d| < 1e-8 (see vr_plane_t_r) */
     uint32_t lo, hi, c, idx, d;
     uint32_t checked; /* reference-defined node checks so far */
+    uint32_t k, in3;  /* while popping: level of the box in [lo, hi), and per axis whether it holds the cell */
 };
 
 /* the ray enters at t (inside the root box): SpaceTracker.new, src/SlimKDT.zig:55-64 */
@@ -103,13 +104,11 @@ VR_HD uint32_t vr_wide_descend(VrWideLane &L, const VrViewK &v, uint32_t iso, co
     return VR_GO_MORE;
 }
 
-/* MOVE (src/raytrace.zig:199-246) out of the box of the excluded node, then the reference's restart at the root
- * folded into a step to the other child of the lowest ancestor that holds the new point.  Returns false when
- * the point has left the root box (the ray is a miss). */
-template <class Path>
-VR_HD bool vr_wide_move(VrWideLane &L, const VrViewK &v, Path &path, uint32_t &escapes)
+/* MOVE (src/raytrace.zig:199-246) out of the box of the excluded node.  Returns false when the point has left
+ * the root box (the ray is a miss); otherwise vr_wide_pop comes next. */
+VR_HD bool vr_wide_move(VrWideLane &L, const VrViewK &v, uint32_t &escapes)
 {
-    uint32_t lo = L.lo, hi = L.hi;
+    const uint32_t lo = L.lo, hi = L.hi;
     const float lx = (float)(lo & 0x3ffu), ly = (float)((lo >> 10) & 0x3ffu), lz = (float)(lo >> 20);
     const float hx = (float)(hi & 0x3ffu), hy = (float)((hi >> 10) & 0x3ffu), hz = (float)(hi >> 20);
     /* the three divisions by a per-ray reciprocal with FMA corrections (vr_div: bit-identical to the IEEE
@@ -131,15 +130,31 @@ VR_HD bool vr_wide_move(VrWideLane &L, const VrViewK &v, Path &path, uint32_t &e
     if (!vr_root_contains(v, px, py, pz)) return false;
     const uint32_t c = vr_pack10((uint32_t)px, (uint32_t)py, (uint32_t)pz);
     L.c = c;
-    /* undo splits until the box holds the new cell (for a point inside the root box, lo <= cell < hi on the
-     * integer cell is Range.containsFloat on the point) */
     uint32_t in3 = 0;
     for (uint32_t a = 0; a < 3u; a++) {
         const uint32_t ca = vr_wide_field(c, a * 10u);
         in3 |= (vr_wide_field(lo, a * 10u) <= ca && ca < vr_wide_field(hi, a * 10u) ? 1u : 0u) << a;
     }
-    uint32_t k = L.d, e = 0;
-    while (in3 != 7u && k > 0u) {
+    L.in3 = in3;
+    L.k = L.d;
+    return true;
+}
+
+/* The reference's restart at the root after a MOVE, folded into a step to the other child of the lowest ancestor
+ * that holds the new point: undo splits from the bottom (at most max_trips of them per call) until the box holds
+ * the new cell -- for a point inside the root box, lo <= cell < hi on the integer cell is Range.containsFloat on
+ * the point -- then credit the checks of levels 0..k and take the child on the point's side.  Returns false when
+ * the budget ran out first (call again). */
+template <class Path>
+VR_HD bool vr_wide_pop(VrWideLane &L, Path &path, uint32_t max_trips)
+{
+    uint32_t lo = L.lo, hi = L.hi, in3 = L.in3, k = L.k, e = 0;
+    const uint32_t c = L.c;
+    for (uint32_t trip = 0; in3 != 7u && k > 0u; trip++) {
+        if (trip == max_trips) {
+            L.lo = lo; L.hi = hi; L.in3 = in3; L.k = k;
+            return false;
+        }
         k--;
         e = path.get(k);
         const uint32_t axis = (e >> 10) & 3u, sh = (e >> 12) & 31u, old = (e >> 18) & 0x3ffu;
@@ -164,7 +179,8 @@ VR_HD bool vr_wide_move(VrWideLane &L, const VrViewK &v, Path &path, uint32_t &e
 
 /* one whole ray */
 template <class NodeFetch, class Path>
-VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Path &path)
+VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Path &path,
+                          uint32_t pop_trips = 64u)
 {
     VrHit h;
     h.t = 0.0f; h.flag = 2u; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
@@ -177,7 +193,8 @@ VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, Node
         if (go == VR_GO_HIT) { h.flag = 1u; h.node = L.idx; h.cell = L.c; break; }
         if (L.checked > VR_MAX_CHECKED) { h.error = 1; break; } /* safety valve, never reached on a valid tree */
         h.moves++;
-        if (!vr_wide_move(L, v, path, h.escapes)) break;
+        if (!vr_wide_move(L, v, h.escapes)) break;
+        while (!vr_wide_pop(L, path, pop_trips)) {}
     }
     h.t = L.t;
     h.checked = L.checked;
