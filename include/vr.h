@@ -241,6 +241,20 @@ int vr_render_device(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint3
                      uint32_t row_begin, uint32_t row_end, void *d_rgb24, void *d_stats,
                      const vr_taps *d_taps, void *stream);
 
+/* One host thread driving several contexts -- normally one per GPU of the node, each holding the same tree
+ * (contexts on one device work too).  The iso loop of src/main.zig:111-138 is split over the contexts with no
+ * exchange between them: VR_SHARD_ISO gives context i a contiguous block of the iso values (whole frames),
+ * VR_SHARD_ROWS a contiguous block of the rows of every frame; the first (count mod n) contexts get one more.
+ * All contexts render at the same time (vr_render_device on their own streams); their parts are copied straight
+ * into place in the HOST buffers, which end up exactly as vr_render_sweep on one context leaves them (allocate
+ * rgb24_out with vr_alloc_host for overlapping copies).  stats_out (iso_count records, may be NULL) holds the
+ * per-iso counters summed over the contexts.  No counterpart in the reference, which is single-threaded on one
+ * CPU; for the one-process-per-GPU form use vr_render_device under any launcher (bench.py does). */
+#define VR_SHARD_ISO 0
+#define VR_SHARD_ROWS 1
+int vr_mgpu_render_sweep(vr_ctx *const *ctxs, uint32_t n_ctx, const vr_view *view, uint32_t iso_begin,
+                         uint32_t iso_count, int shard, uint8_t *rgb24_out, vr_render_stats *stats_out);
+
 /* Blocks until everything enqueued on the context's own stream has finished. */
 int vr_sync(vr_ctx *ctx);
 

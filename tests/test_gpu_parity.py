@@ -437,3 +437,32 @@ def test_vr_bench_driver_reproduces_reference_renders(tmp_path, golden_gray):
             img = np.asarray(PIL.open(tmp_path / ("out_iso%d.png" % iso)).convert("RGB"))
             assert (img[..., 0] == golden_gray[iso]).all() and (img[..., 1] == img[..., 0]).all()
             os.remove(tmp_path / ("out_iso%d.png" % iso))
+
+
+@pytest.mark.parametrize("shard", ["iso", "rows"])
+def test_one_thread_several_contexts_equal_one_context(oracle, c60_vox, c60_tree, c60_renderer, shard):
+    """vr_mgpu_render_sweep: the iso loop split over three contexts by one host thread (all on device 0 here; one
+    per GPU on a node) leaves frames and per-iso counters exactly as one context does -- uneven splits, more
+    contexts than frames, page-locked and pageable output."""
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    extra = [vr.Renderer(0) for _ in range(2)]
+    try:
+        for r in extra:
+            r.upload_kdt(vr.SlimKDT(nodes, rd))
+        group = [c60_renderer] + extra
+        for W, H, b, n, pinned in [(200, 131, 90, 7, False), (64, 50, 100, 2, True), (96, 2, 0, 256, False)]:
+            one = c60_renderer.renderSweep(pos, forw, up, W, H, 2.0, b, n)
+            out = c60_renderer.pinned_frames(n, H, W) if pinned else None
+            got = vr.raytrace.renderSweepMulti(group, pos, forw, up, W, H, 2.0, b, n, shard=shard, out=out)
+            assert (got["rgb"] == one["rgb"]).all(), (W, H, b, n)
+            assert got["stats"] == one["stats"], (W, H, b, n)
+        L = capi.lib()
+        v = vr.raytrace._view(pos, forw, up, 8, 8, 2.0)
+        buf = np.zeros((1, 8, 8, 3), np.uint8)
+        twice = (C.c_void_p * 2)(c60_renderer.handle, c60_renderer.handle)
+        assert L.vr_mgpu_render_sweep(twice, 2, C.byref(v), 0, 1, 0, buf.ctypes.data, None) == capi.VR_EARG
+        assert L.vr_mgpu_render_sweep(twice, 1, C.byref(v), 0, 1, 2, buf.ctypes.data, None) == capi.VR_EARG
+    finally:
+        for r in extra:
+            r.close()

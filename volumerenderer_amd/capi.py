@@ -15,6 +15,7 @@ VR_ETREE = -8
 VR_EHIP_BASE = -1000
 FLAG_MISS, FLAG_HIT, FLAG_OOB = 0, 1, 2
 
+SHARD_ISO, SHARD_ROWS = 0, 1
 KERNEL_DEFAULT, KERNEL_RESTART_GLOBAL, KERNEL_RESTART_LDS, KERNEL_RESUME, KERNEL_PIPELINE, KERNEL_SWEEP = 0, 1, 2, 3, 4, 5
 
 HEURISTICS = {
@@ -37,7 +38,7 @@ HEURISTICS = {
 EXPORTS = [
     "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_host_check_kdt_wide", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_alloc_host", "vr_free_host", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
     "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_upload_kdt_wide", "vr_download_kdt_wide", "vr_render",
-    "vr_render_sweep", "vr_render_device", "vr_sync", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
+    "vr_render_sweep", "vr_render_device", "vr_mgpu_render_sweep", "vr_sync", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
 ]
 
@@ -120,6 +121,8 @@ def lib():
                                   C.POINTER(Taps)]
     L.vr_render_device.argtypes = [vp, C.POINTER(View), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp,
                                    C.POINTER(Taps), vp]
+    L.vr_mgpu_render_sweep.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(View), C.c_uint32, C.c_uint32, C.c_int, vp,
+                                       C.POINTER(RenderStats)]
     L.vr_sync.argtypes = [vp]
     L.vr_set_timing.argtypes = [vp, C.c_int]
     L.vr_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]

@@ -129,7 +129,7 @@ int vr_alloc_host(size_t bytes, void **out)
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VR_ENODEVICE;
-    VR_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    VR_HIP(hipHostMalloc(out, bytes, hipHostMallocPortable)); /* page-locked for every device of the process */
     return VR_OK;
 }
 
@@ -448,6 +448,69 @@ int vr_render(vr_ctx *c, const vr_view *view, uint8_t isoval, uint8_t *rgb24_out
               const vr_taps *taps)
 {
     return vr_render_sweep(c, view, isoval, 1, rgb24_out, stats_out, taps);
+}
+
+int vr_mgpu_render_sweep(vr_ctx *const *ctxs, uint32_t n_ctx, const vr_view *view, uint32_t iso_begin, uint32_t iso_count,
+                         int shard, uint8_t *rgb24_out, vr_render_stats *stats_out)
+{
+    if (!ctxs || n_ctx == 0 || n_ctx > 64u || !rgb24_out) return VR_EARG;
+    if (shard != VR_SHARD_ISO && shard != VR_SHARD_ROWS) return VR_EARG;
+    int rc = check_view(view);
+    if (rc != VR_OK) return rc;
+    if (iso_count == 0 || iso_begin > 255u || iso_begin + iso_count > 256u) return VR_EARG;
+    for (uint32_t i = 0; i < n_ctx; i++) {
+        if (!ctxs[i]) return VR_EARG;
+        if (!ctxs[i]->d_nodes) return VR_ESTATE;
+        for (uint32_t j = 0; j < i; j++)
+            if (ctxs[j] == ctxs[i]) return VR_EARG; /* a context renders one part at a time */
+    }
+    const size_t row_bytes = (size_t)view->width * 3u, frame_bytes = row_bytes * view->height;
+    const uint32_t total = shard == VR_SHARD_ISO ? iso_count : view->height;
+    struct Part { uint32_t iso_b, iso_n, r0, r1; };
+    Part part[64];
+    /* enqueue everything first, so that all devices work at the same time */
+    for (uint32_t i = 0; i < n_ctx; i++) {
+        const uint32_t base = total / n_ctx, rem = total % n_ctx;
+        const uint32_t begin = i * base + (i < rem ? i : rem), count = base + (i < rem ? 1u : 0u);
+        Part &p = part[i];
+        if (shard == VR_SHARD_ISO) { p.iso_b = iso_begin + begin; p.iso_n = count; p.r0 = 0; p.r1 = view->height; }
+        else { p.iso_b = iso_begin; p.iso_n = iso_count; p.r0 = begin; p.r1 = begin + count; }
+        if (count == 0) continue; /* more contexts than frames / rows */
+        vr_ctx *c = ctxs[i];
+        VR_HIP(hipSetDevice(c->device));
+        const size_t part_frame = row_bytes * (p.r1 - p.r0);
+        rc = ensure((void **)&c->d_rgb, &c->rgb_cap, part_frame * p.iso_n);
+        if (rc != VR_OK) return rc;
+        rc = ensure((void **)&c->d_stats, &c->stats_cap, sizeof(vr_render_stats) * p.iso_n);
+        if (rc != VR_OK) return rc;
+        rc = vr_render_device(c, view, p.iso_b, p.iso_n, p.r0, p.r1, c->d_rgb, c->d_stats, nullptr, c->stream);
+        if (rc != VR_OK) return rc;
+        /* frame k of the part: rows [r0, r1) of frame (iso_b - iso_begin + k) of the output */
+        uint8_t *dst = rgb24_out + (size_t)(p.iso_b - iso_begin) * frame_bytes + (size_t)p.r0 * row_bytes;
+        VR_HIP(hipMemcpy2DAsync(dst, frame_bytes, c->d_rgb, part_frame, part_frame, p.iso_n, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (stats_out) std::memset(stats_out, 0, sizeof(vr_render_stats) * iso_count);
+    std::vector<vr_render_stats> tmp;
+    for (uint32_t i = 0; i < n_ctx; i++) {
+        const Part &p = part[i];
+        if ((shard == VR_SHARD_ISO ? p.iso_n : p.r1 - p.r0) == 0) continue;
+        vr_ctx *c = ctxs[i];
+        VR_HIP(hipSetDevice(c->device));
+        if (stats_out) {
+            tmp.resize(p.iso_n);
+            VR_HIP(hipMemcpyAsync(tmp.data(), c->d_stats, sizeof(vr_render_stats) * p.iso_n, hipMemcpyDeviceToHost, c->stream));
+        }
+        VR_HIP(hipStreamSynchronize(c->stream));
+        if (stats_out)
+            for (uint32_t k = 0; k < p.iso_n; k++) {
+                vr_render_stats &o = stats_out[p.iso_b - iso_begin + k];
+                const vr_render_stats &s = tmp[k];
+                o.nodes_checked += s.nodes_checked; o.hit_count += s.hit_count; o.miss_count += s.miss_count;
+                o.oob_count += s.oob_count; o.escape_help_events += s.escape_help_events; o.moves += s.moves;
+                o.errors += s.errors;
+            }
+    }
+    return VR_OK;
 }
 
 int vr_sync(vr_ctx *c)

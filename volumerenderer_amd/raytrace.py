@@ -157,6 +157,22 @@ class Renderer:
         return res
 
 
+def renderSweepMulti(renderers, src, forw, up, width, height, viewport_width, iso_begin, iso_count, shard="iso", out=None):
+    """The iso loop split over several Renderers (normally one per GPU, the same tree in each) by ONE host thread:
+    vr_mgpu_render_sweep.  shard = "iso" (blocks of whole frames) or "rows" (a block of rows of every frame).
+    Returns dict(rgb[iso,h,w,3], stats[list]) exactly as renderSweep on one Renderer does."""
+    L = capi.lib()
+    v = _view(src, forw, up, width, height, viewport_width)
+    rgb = out if out is not None else np.zeros((iso_count, height, width, 3), dtype=np.uint8)
+    assert rgb.shape == (iso_count, height, width, 3) and rgb.dtype == np.uint8 and rgb.flags.c_contiguous
+    stats = (capi.RenderStats * iso_count)()
+    handles = (C.c_void_p * len(renderers))(*[r.handle for r in renderers])
+    capi.check(L.vr_mgpu_render_sweep(handles, len(renderers), C.byref(v), int(iso_begin), int(iso_count),
+                                      capi.SHARD_ROWS if shard == "rows" else capi.SHARD_ISO, rgb.ctypes.data, stats),
+               "vr_mgpu_render_sweep")
+    return {"rgb": rgb, "stats": [stats[i].as_dict() for i in range(iso_count)]}
+
+
 def renderImage(src, forw, up, img, viewport_width, kdt, isoval, device=0):
     """One-shot form with the reference's argument order (src/raytrace.zig:11-21)."""
     with Renderer(device) as r:
