@@ -51,6 +51,8 @@ pub extern fn vr_upload_kdt_wide(ctx: ?*Ctx, nodes: [*]const u32, n_slots: u64, 
 pub extern fn vr_download_kdt_wide(ctx: ?*Ctx, nodes_out: ?[*]u32, first_slot: u64, n_slots: u64, n_slots_out: ?*u64, root_dim_out: ?*[3]u16) c_int;
 pub extern fn vr_save_kdt(path: [*:0]const u8, nodes: [*]const u32, n_slots: u64, root_dim: *const [3]u8) c_int;
 pub extern fn vr_load_kdt(path: [*:0]const u8, nodes_out: *?[*]u32, n_slots_out: *u64, root_dim_out: *[3]u8) c_int;
+// one host thread, one context per GPU: shard = 0 splits the iso values, 1 the rows of every frame
+pub extern fn vr_mgpu_render_sweep(ctxs: [*]const ?*Ctx, n_ctx: u32, view: *const View, iso_begin: u32, iso_count: u32, shard: c_int, rgb24_out: [*]u8, stats_out: ?[*]RenderStats) c_int;
 pub extern fn vr_free(p: ?*anyopaque) void;
 pub extern fn vr_render(ctx: ?*Ctx, view: *const View, isoval: u8, rgb24_out: [*]u8, stats_out: ?*RenderStats, taps: ?*const anyopaque) c_int;
 pub extern fn vr_render_sweep(ctx: ?*Ctx, view: *const View, iso_begin: u32, iso_count: u32, rgb24_out: [*]u8, stats_out: ?[*]RenderStats, taps: ?*const anyopaque) c_int;
