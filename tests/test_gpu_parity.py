@@ -427,7 +427,8 @@ def test_vr_bench_driver_reproduces_reference_renders(tmp_path, golden_gray):
     PIL = pytest.importorskip("PIL.Image")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "volumerenderer_amd", "vr_bench")
-    for extra, lo, hi in [([], 97, 103), (["--sweep"], 90, 110)]:
+    for extra, lo, hi in [([], 97, 103), (["--sweep"], 90, 110), (["--gpus", "3", "--shard", "rows"], 95, 102),
+                          (["--gpus", "2"], 99, 104)]:
         out = subprocess.run([exe, "--volume", os.path.join(root, "tests", "data", "C60.vol"), "--size", "512", "--iso",
                               "%d:%d" % (lo, hi), "--heuristics", "center", "--out", str(tmp_path)] + extra,
                              capture_output=True, text=True, timeout=120)

@@ -7,6 +7,9 @@
  *
  *   vr_bench [--volume C60.vol] [--size 512] [--iso 0:256] [--heuristics main|center|all]
  *            [--out DIR | --no-images] [--sweep] [--device 0] [--viewport 2.0] [--camera x,y,z]
+ *            [--gpus N [--shard iso|rows]]
+ * --gpus N (implies --sweep): N contexts, on devices 0..N-1 as far as the node has them (beyond that the
+ * devices are used again), driven by this one thread through vr_mgpu_render_sweep.
  */
 #include <chrono>
 #include <cstdio>
@@ -50,6 +53,7 @@ int main(int argc, char **argv)
     int device = 0;
     bool images = true;
     bool sweep = false; /* the whole iso loop in one vr_render_sweep call (frames into page-locked memory) */
+    int n_gpus = 1, shard = VR_SHARD_ISO;
     float viewport = 2.0f, cam[3] = { -30.0f, -300.0f, -30.0f }; /* src/main.zig:37,126 */
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -62,10 +66,13 @@ int main(int argc, char **argv)
         else if (a == "--no-images") images = false;
         else if (a == "--sweep") sweep = true;
         else if (a == "--device") device = std::atoi(next());
+        else if (a == "--gpus") { n_gpus = std::atoi(next()); sweep = true; }
+        else if (a == "--shard") { std::string m = next(); shard = m == "rows" ? VR_SHARD_ROWS : VR_SHARD_ISO; }
         else if (a == "--viewport") viewport = (float)std::atof(next());
         else if (a == "--camera") { if (std::sscanf(next(), "%f,%f,%f", &cam[0], &cam[1], &cam[2]) != 3) { std::fprintf(stderr, "--camera x,y,z\n"); return 2; } }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
+    if (n_gpus < 1 || n_gpus > 64) { std::fprintf(stderr, "--gpus 1..64\n"); return 2; }
     if (iso_end > 256 || iso_begin >= iso_end || size == 0) { std::fprintf(stderr, "bad --iso / --size\n"); return 2; }
 
     std::printf("Loading dataset: '%s'\n", volume.c_str());
@@ -88,6 +95,17 @@ int main(int argc, char **argv)
 
     vr_ctx *ctx = nullptr;
     CHECK(vr_ctx_create(device, &ctx));
+    std::vector<vr_ctx *> group(1, ctx);
+    for (int g = 1, n_dev = 0; g < n_gpus; g++) {
+        vr_ctx *more = nullptr;
+        int rc = n_dev ? VR_EARG : vr_ctx_create(device + g, &more);
+        if (rc == VR_EARG) { /* no such device: go round the ones there are */
+            if (!n_dev) n_dev = g;
+            rc = vr_ctx_create(device + g % n_dev, &more);
+        }
+        CHECK(rc);
+        group.push_back(more);
+    }
     std::vector<uint8_t> img((size_t)size * size * 3u);
     double tot_time_balanced = 0.0;
     const uint32_t n_iso = iso_end - iso_begin;
@@ -98,7 +116,7 @@ int main(int argc, char **argv)
         uint8_t root_dim[3];
         vr_build_stats bs;
         int rc = vr_host_build_kdt(vox, res, list[hi].first, (uint64_t)1 << 30, &nodes, &n_slots, root_dim, &bs);
-        if (rc == VR_OK) rc = vr_upload_kdt(ctx, nodes, n_slots, root_dim);
+        for (size_t g = 0; g < group.size() && rc == VR_OK; g++) rc = vr_upload_kdt(group[g], nodes, n_slots, root_dim);
         if (rc != VR_OK) { /* src/main.zig:100-104 */
             std::printf("\n FAILD TO BUILD KDT! (%s)\n", vr_strerror(rc));
             vr_free(nodes);
@@ -118,7 +136,10 @@ int main(int argc, char **argv)
             CHECK(vr_alloc_host(frame * n_iso, &frames));
             std::vector<vr_render_stats> st(n_iso);
             const auto t0 = std::chrono::steady_clock::now();
-            CHECK(vr_render_sweep(ctx, &view, iso_begin, n_iso, (uint8_t *)frames, st.data(), nullptr));
+            if (group.size() > 1)
+                CHECK(vr_mgpu_render_sweep(group.data(), (uint32_t)group.size(), &view, iso_begin, n_iso, shard, (uint8_t *)frames, st.data()));
+            else
+                CHECK(vr_render_sweep(ctx, &view, iso_begin, n_iso, (uint8_t *)frames, st.data(), nullptr));
             const auto t1 = std::chrono::steady_clock::now();
             tot_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
             for (uint32_t k = 0; k < n_iso; k++) {
@@ -153,7 +174,7 @@ int main(int argc, char **argv)
                     (unsigned long long)(node_checks / 1000000ull), tot_time_balanced > 0 ? tot_ms / tot_time_balanced : 0.0);
         std::printf("Mrays/s (host-timed, frames copied to the host): %.1f\n", (double)size * size * n_iso / (tot_ms * 1e-3) / 1e6);
     }
-    vr_ctx_destroy(ctx);
+    for (vr_ctx *c : group) vr_ctx_destroy(c);
     vr_free(vox);
     return 0;
 }
