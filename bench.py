@@ -6,7 +6,7 @@ One step = one pass of the hot path over one batch of work: the reference driver
 reference camera (src/main.zig:31-43), i.e. 256 x 1 048 576 primary rays per step.  All primary
 rays count, including the ones that miss the volume -- the reference's ms/frame includes them too.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--gather]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--gather] [--in-flight F]
                     [--shard iso|rows] [--kernel V] [--width PX] [--volume skull|c60|standin256|gyroid1024]
                     [--iso-begin B] [--iso-count N] [--no-cpu-baseline]
 
@@ -141,6 +141,10 @@ def main():
     ap.add_argument("--iso-begin", type=int, default=0)
     ap.add_argument("--iso-count", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="independent steps in flight per rank (own context, stream and frame buffer each): with 2, the "
+                         "tail of one sweep, where its last long rays leave CUs idle, overlaps the start of the next; "
+                         "the default 1 runs the steps strictly one after the other")
     args = ap.parse_args()
 
     import numpy as np
@@ -216,10 +220,25 @@ def main():
     d_rgb = torch.empty((iso_count, row_end - row_begin, W, 3), dtype=torch.uint8, device="cuda")
     d_stats = torch.zeros((iso_count, 7), dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    # --in-flight > 1: further slots, each with its own context (scratch), stream and output buffers
+    if args.in_flight < 1 or (args.in_flight > 1 and args.gather):
+        raise SystemExit("--in-flight must be >= 1 and does not go with --gather")
+    slots = [(r, d_rgb, d_stats, None)]
+    for _ in range(1, args.in_flight):
+        r2 = vr.Renderer(local_rank)
+        r2.upload_volume(data)
+        r2.build_kdt("AlwaysCenter")
+        r2.set_kernel(args.kernel)
+        s2 = torch.cuda.Stream()
+        slots.append((r2, torch.empty_like(d_rgb), torch.zeros_like(d_stats), s2))
+    step_no = [0]
 
     def step():
-        capi.check(L.vr_render_device(r.handle, C.byref(view), iso_begin, iso_count, row_begin, row_end, d_rgb.data_ptr(),
-                                      d_stats.data_ptr(), None, C.c_void_p(stream)), "vr_render_device")
+        rr, rgb_k, stats_k, s_k = slots[step_no[0] % len(slots)]
+        step_no[0] += 1
+        capi.check(L.vr_render_device(rr.handle, C.byref(view), iso_begin, iso_count, row_begin, row_end, rgb_k.data_ptr(),
+                                      stats_k.data_ptr(), None, C.c_void_p(s_k.cuda_stream if s_k else stream)),
+                   "vr_render_device")
         if args.gather and world > 1:
             sharding.gather_frames(d_rgb.cpu() if rehearsal else d_rgb, counts, dst=0)
 
@@ -241,6 +260,16 @@ def main():
     capi.check(L.vr_set_timing(r.handle, 0), "vr_set_timing")
     tot_ms, launches = C.c_double(), C.c_uint32()
     capi.check(L.vr_timing_read(r.handle, C.byref(tot_ms), C.byref(launches)), "vr_timing_read")
+    if args.in_flight > 1:
+        # kernels of overlapping steps wait for each other's CUs, so their event intervals say nothing about the
+        # kernel: time it in a short pass of its own, one step after the other (outside the timed region)
+        capi.check(L.vr_set_timing(r.handle, 1), "vr_set_timing")
+        for _ in range(3):
+            step_no[0] = 0
+            step()
+            torch.cuda.synchronize()
+        capi.check(L.vr_set_timing(r.handle, 0), "vr_set_timing")
+        capi.check(L.vr_timing_read(r.handle, C.byref(tot_ms), C.byref(launches)), "vr_timing_read")
 
     t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -305,6 +334,7 @@ def main():
                                   "moves `traffic` bytes per launch"),
                          "counters": profile_counters() if (args.volume == "skull" and W == 1024 and IN == 256) else None},
             "errors": errors,
+            "steps_in_flight": args.in_flight,
         }
         if rehearsal:
             out["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
@@ -319,6 +349,8 @@ def main():
             threads = max(1, min(16, len(os.sched_getaffinity(0))))
             out["cpu_all_cores"] = cpu_all_cores(kdt, pos, forw, up, W, threads, I0, IN)
         print(json.dumps(out), flush=True)
+    for extra in slots[1:]:
+        extra[0].close()
     r.close()
     if world > 1:
         dist.barrier()
