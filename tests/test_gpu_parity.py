@@ -467,3 +467,31 @@ def test_one_thread_several_contexts_equal_one_context(oracle, c60_vox, c60_tree
     finally:
         for r in extra:
             r.close()
+
+
+def test_bench_line_has_the_contract_fields():
+    """bench.py prints one JSON line; the keys the harness reads must all be there (small image, 2 steps)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "256"],
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [x for x in out.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Mrays/s" and d["errors"] == 0
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-9
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
+    assert d["value"] > 100 * d["cpu_baseline"]["value"]

@@ -1,5 +1,5 @@
 """Times single-frame renders (one iso value per call, frames resident on the device): the reference's
-ms/frame figure (src/main.zig:147-161) for this library.  usage: python tools/frame_time.py [width]"""
+ms/frame figure (src/main.zig:147-161) for this library.  usage: python tools/frame_time.py [width] [kernel variant]"""
 import ctypes as C
 import os
 import sys
@@ -19,6 +19,8 @@ L = capi.lib()
 with vr.Renderer(0) as r:
     r.upload_volume(data)
     r.build_kdt("AlwaysCenter")
+    if len(sys.argv) > 2:
+        r.set_kernel(int(sys.argv[2]))
     view = vr.raytrace._view(pos, forw, up, W, W, 2.0)
     d_rgb = torch.empty((1, W, W, 3), dtype=torch.uint8, device="cuda")
     d_stats = torch.zeros((1, 7), dtype=torch.int64, device="cuda")
