@@ -187,9 +187,10 @@ int vr_upload_volume(vr_ctx *ctx, const uint8_t *vox, uint32_t rx, uint32_t ry, 
  * with vr_host_prepare_kdt first: VR_ETREE for a tree the reference could not traverse either. */
 int vr_upload_kdt(vr_ctx *ctx, const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3]);
 
-/* SlimKDT.newHeursiticPartition on the uploaded volume, result kept on the device.
- * VR_H_ALWAYS_CENTER is built on the GPU; other heuristics are built by vr_host_build_kdt and
- * uploaded. */
+/* SlimKDT.newHeursiticPartition (src/SlimKDT.zig:222-322) on the uploaded volume, built on the GPU and kept
+ * there: the centre split in two data-parallel passes, the span heuristics (:327-598) level by level.  The
+ * node array is word for word what vr_host_build_kdt produces (2^(depth+1) slots).  VR_ETOODEEP where a heap
+ * index would pass 2^32: the reference's "FAILD TO BUILD KDT" case (src/main.zig:100-104). */
 int vr_build_kdt(vr_ctx *ctx, int heuristic, vr_build_stats *stats_out);
 
 /* Copies the device-resident tree back (for parity checks and caching). nodes_out may be NULL to

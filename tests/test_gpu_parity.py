@@ -428,7 +428,7 @@ def test_vr_bench_driver_reproduces_reference_renders(tmp_path, golden_gray):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "volumerenderer_amd", "vr_bench")
     for extra, lo, hi in [([], 97, 103), (["--sweep"], 90, 110), (["--gpus", "3", "--shard", "rows"], 95, 102),
-                          (["--gpus", "2"], 99, 104)]:
+                          (["--gpus", "2"], 99, 104), (["--gpu-build", "--sweep"], 100, 103)]:
         out = subprocess.run([exe, "--volume", os.path.join(root, "tests", "data", "C60.vol"), "--size", "512", "--iso",
                               "%d:%d" % (lo, hi), "--heuristics", "center", "--out", str(tmp_path)] + extra,
                              capture_output=True, text=True, timeout=120)
@@ -495,3 +495,45 @@ def test_bench_line_has_the_contract_fields():
         assert key in d["cpu_baseline"], key
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
     assert d["value"] > 100 * d["cpu_baseline"]["value"]
+
+
+SPAN_HEURISTICS = ["MinimizeSpan", "FlexibleFirst5", "FlexibleFirst10", "FlexibleAfter10", "FlexibleAfter15",
+                   "FlexibleAfter20", "FlexibleCenterWeighted5", "FlexibleCenterWeighted10", "FlexibleCenterWeighted30",
+                   "FlexibleCenterWeighted50", "FlexibleCenterWeighted75", "FlexibleCenterWeighted100"]
+
+
+def test_gpu_span_heuristic_trees_match_host_builder_and_oracle(oracle, c60_vox, skull_vox):
+    """The span heuristics built on the GPU level by level: the node array, the statistics and the failure case are
+    those of the host builder (and through tests/test_host_builder.py of the oracle), word for word."""
+    rng = np.random.default_rng(33)
+    cases = [(c60_vox[20:40, 18:40, 20:38], SPAN_HEURISTICS), (random_volume(rng, (9, 30, 5), "noise"), SPAN_HEURISTICS),
+             (random_volume(rng, (40, 37, 44), "smooth"), SPAN_HEURISTICS[1:]), (random_volume(rng, (2, 2, 2), "noise"), SPAN_HEURISTICS[:3]),
+             (c60_vox, ["FlexibleFirst5", "FlexibleAfter15", "FlexibleCenterWeighted50", "FlexibleCenterWeighted100"]),
+             (skull_vox, ["FlexibleFirst5", "FlexibleCenterWeighted100"])]
+    built = 0
+    for vox, heuristics in cases:
+        vox = np.ascontiguousarray(vox)
+        with vr.Renderer(0) as r:
+            r.upload_volume(vr.Data(vox))
+            for h in heuristics:
+                try:
+                    k = vr.SlimKDT.newHeursiticPartition(vr.Data(vox), h)
+                except capi.VrError as e:
+                    assert e.code == capi.VR_ETOODEEP
+                    with pytest.raises(capi.VrError) as g:
+                        r.build_kdt(h)
+                    assert g.value.code == capi.VR_ETOODEEP, (vox.shape, h)
+                    continue
+                bs = r.build_kdt(h)
+                got, grd = r.download_kdt()
+                assert (bs.layer_count, bs.number_of_nodes, bs.non_center_partition_count) == (
+                    k.build.layer_count, k.build.number_of_nodes, k.build.non_center_partition_count), (vox.shape, h)
+                n = min(len(got), len(k.nodes))
+                assert (got[:n] == k.nodes[:n]).all() and not got[n:].any() and not k.nodes[n:].any(), (vox.shape, h)
+                assert (grd == k.root_dim).all()
+                built += 1
+            # the tree built last renders like the oracle walking the host-built one
+            pos, forw, up = oracle.main_camera(vox.shape)
+            ref = oracle.render(k.nodes, k.root_dim, pos, forw, up, 96, 96, 2.0, 100)
+            assert_same_render(_gpu(r, pos, forw, up, 96, 96, 2.0, 100), ref, "GPU-built %s tree" % h)
+    assert built >= 25

@@ -7,7 +7,8 @@
  *
  *   vr_bench [--volume C60.vol] [--size 512] [--iso 0:256] [--heuristics main|center|all]
  *            [--out DIR | --no-images] [--sweep] [--device 0] [--viewport 2.0] [--camera x,y,z]
- *            [--gpus N [--shard iso|rows]]
+ *            [--gpus N [--shard iso|rows]] [--gpu-build]
+ * --gpu-build: trees are built on the GPU (vr_upload_volume + vr_build_kdt) instead of by the host builder.
  * --gpus N (implies --sweep): N contexts, on devices 0..N-1 as far as the node has them (beyond that the
  * devices are used again), driven by this one thread through vr_mgpu_render_sweep.
  */
@@ -54,6 +55,7 @@ int main(int argc, char **argv)
     bool images = true;
     bool sweep = false; /* the whole iso loop in one vr_render_sweep call (frames into page-locked memory) */
     int n_gpus = 1, shard = VR_SHARD_ISO;
+    bool gpu_build = false;
     float viewport = 2.0f, cam[3] = { -30.0f, -300.0f, -30.0f }; /* src/main.zig:37,126 */
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -66,6 +68,7 @@ int main(int argc, char **argv)
         else if (a == "--no-images") images = false;
         else if (a == "--sweep") sweep = true;
         else if (a == "--device") device = std::atoi(next());
+        else if (a == "--gpu-build") gpu_build = true;
         else if (a == "--gpus") { n_gpus = std::atoi(next()); sweep = true; }
         else if (a == "--shard") { std::string m = next(); shard = m == "rows" ? VR_SHARD_ROWS : VR_SHARD_ISO; }
         else if (a == "--viewport") viewport = (float)std::atof(next());
@@ -115,8 +118,16 @@ int main(int argc, char **argv)
         uint64_t n_slots = 0;
         uint8_t root_dim[3];
         vr_build_stats bs;
-        int rc = vr_host_build_kdt(vox, res, list[hi].first, (uint64_t)1 << 30, &nodes, &n_slots, root_dim, &bs);
-        for (size_t g = 0; g < group.size() && rc == VR_OK; g++) rc = vr_upload_kdt(group[g], nodes, n_slots, root_dim);
+        int rc = VR_OK;
+        if (gpu_build) {
+            for (size_t g = 0; g < group.size() && rc == VR_OK; g++) {
+                rc = vr_upload_volume(group[g], vox, res[0], res[1], res[2]);
+                if (rc == VR_OK) rc = vr_build_kdt(group[g], list[hi].first, &bs);
+            }
+        } else {
+            rc = vr_host_build_kdt(vox, res, list[hi].first, (uint64_t)1 << 30, &nodes, &n_slots, root_dim, &bs);
+            for (size_t g = 0; g < group.size() && rc == VR_OK; g++) rc = vr_upload_kdt(group[g], nodes, n_slots, root_dim);
+        }
         if (rc != VR_OK) { /* src/main.zig:100-104 */
             std::printf("\n FAILD TO BUILD KDT! (%s)\n", vr_strerror(rc));
             vr_free(nodes);

@@ -289,15 +289,23 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
     }
     if (!c->h_vox) return VR_ESTATE;
     if (heuristic != VR_H_ALWAYS_CENTER) {
-        /* span heuristics: host builder, then the ordinary upload path */
-        uint32_t *nodes = nullptr;
-        uint64_t n_slots = 0;
-        uint8_t rd[3];
-        int rc = vr_host_build_kdt(c->h_vox, c->res, heuristic, 0, &nodes, &n_slots, rd, stats_out);
-        if (rc != VR_OK) return rc;
-        rc = vr_upload_kdt(c, nodes, n_slots, rd);
-        vr_free(nodes);
-        return rc;
+        /* span heuristics: built on the device level by level, valid by construction */
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
+        free_prepared(c);
+        c->n_slots = 0;
+        if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
+        uint32_t depth = 0;
+        bool too_deep = false;
+        e = vr_build_span_tree(c->stream, c->d_vox, c->res[0], c->res[1], c->res[2], heuristic, (uint64_t)1 << 32, alloc_within_4g,
+                               &c->d_nodes, &c->d_prepared_raw, &c->d_prepared, &depth, stats_out, &too_deep);
+        if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
+        if (too_deep) return VR_ETOODEEP;
+        c->n_slots = (uint64_t)1 << (depth + 1);
+        c->max_depth = depth;
+        for (int a = 0; a < 3; a++) c->root_dim[a] = c->res[a] - 1u;
+        c->wide = false;
+        return VR_OK;
     }
     /* centre split: built on the device, valid by construction (no host walk, no PCIe traffic) */
     const uint32_t depth = vr_center_tree_depth(c->res[0], c->res[1], c->res[2]);

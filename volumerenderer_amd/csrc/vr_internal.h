@@ -46,6 +46,13 @@ hipError_t vr_launch_build_center(hipStream_t stream, const uint8_t *d_vox, uint
                                   uint32_t depth, uint32_t *d_raw, uint32_t *d_prepared);
 
 
+/* The span heuristics built on the device (vr_build.hip), level by level.  `place` allocates the flattened array
+ * (the C-ABI file places it inside one 4 GiB window). */
+hipError_t vr_build_span_tree(hipStream_t stream, const uint8_t *d_vox, uint32_t rx, uint32_t ry, uint32_t rz, int heuristic,
+                              uint64_t max_slots, hipError_t (*place)(size_t, void **, uint32_t **), uint32_t **raw_out,
+                              void **prepared_raw_out, uint32_t **prepared_out, uint32_t *depth_out, vr_build_stats *stats_out,
+                              bool *too_deep);
+
 /* Volumes beyond 256 voxels per axis, on the wide node array: the pipeline with the wide lane code, or the
  * per-pixel kernel when `variant` names one.  `workspace` as for vr_launch_render.
  * vr_launch_build_center with d_prepared = nullptr builds that array (wide node words) instead. */
