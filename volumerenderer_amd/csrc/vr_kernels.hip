@@ -53,13 +53,7 @@ struct GlobalFetch {
     const uint32_t *nodes;
     __device__ __forceinline__ uint32_t operator()(uint32_t idx) const
     {
-#if defined(VR_TUNE_SC1)
-        return __hip_atomic_load(nodes + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* bypasses the vector L1 */
-#elif defined(VR_TUNE_NT)
-        return __builtin_nontemporal_load(nodes + idx);
-#else
         return nodes[idx];
-#endif
     }
 };
 
@@ -1176,7 +1170,6 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     const size_t trace_stack_bytes = ((size_t)stack_levels + 1u) * kTraceThreads * sizeof(uint32_t);
     const size_t stat_bytes = sweep ? (size_t)sweep_stat_words(iso_count) * sizeof(uint32_t) : 0u;
     uint32_t top_levels = 14;
-    if (const char *tune = getenv("VR_TUNE_TOP_LEVELS")) top_levels = (uint32_t)atoi(tune); /* experiment knob */
     if (top_levels > 14) top_levels = 14;
     while (top_levels > 0 && ((((size_t)1 << top_levels) * sizeof(uint32_t)) + trace_stack_bytes + stat_bytes > lds_limit ||
                               ((uint64_t)1 << top_levels) > view.n_slots + 1u))
