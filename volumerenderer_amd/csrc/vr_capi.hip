@@ -21,6 +21,8 @@
 struct vr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr; /* device-to-host copies of finished frames, next to the rendering of the next ones */
+    hipEvent_t chunk_done[4] = { nullptr, nullptr, nullptr, nullptr }; /* one per chunk of a sweep (256 iso values / 64) */
     /* volume (only the tree builder reads it) */
     uint8_t *d_vox = nullptr;
     uint32_t res[3] = { 0, 0, 0 };
@@ -154,6 +156,8 @@ int vr_ctx_create(int device, vr_ctx **out)
     c->n_cus = prop.multiProcessorCount;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         vr_ctx_destroy(c);
         return VR_EHIP_BASE - (int)e;
@@ -167,6 +171,9 @@ void vr_ctx_destroy(vr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (int i = 0; i < 4; i++)
+        if (c->chunk_done[i]) (void)hipEventDestroy(c->chunk_done[i]);
     if (c->d_vox) (void)hipFree(c->d_vox);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     free_prepared(c);
@@ -440,6 +447,37 @@ int vr_render_sweep(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t
         dt.t = host_tap[1] ? (float *)c->d_tap[1] : nullptr;
         dt.checked = host_tap[2] ? (uint32_t *)c->d_tap[2] : nullptr;
         dt.node = host_tap[3] ? (uint32_t *)c->d_tap[3] : nullptr;
+    }
+    /* A long sweep without taps into page-locked memory (vr_alloc_host) goes in chunks of iso values: while one chunk's frames cross PCIe on the copy stream,
+     * the next chunk renders.  64 iso values per chunk: four such renders (2.4 ms each for Skull at 1024^2, against 4.5 ms
+     * for all 256 in one launch -- shorter sweeps share fewer walks) still stay ahead of the copies, and only the first one
+     * is not hidden behind them. */
+    const uint32_t kChunk = 64;
+    const size_t frame_bytes = (size_t)view->width * view->height * 3;
+    bool page_locked = false; /* pageable destinations are staged by the runtime: chunks only get in each other's way there */
+    {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, rgb24_out) == hipSuccess) page_locked = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError(); /* an ordinary heap pointer is "invalid value" to this query */
+    }
+    if (page_locked && !taps && iso_count >= 2 * kChunk && frame_bytes * kChunk >= ((size_t)32 << 20)) {
+        uint32_t n_chunk = 0;
+        for (uint32_t k = 0; k < iso_count; k += kChunk, n_chunk++) {
+            const uint32_t n = iso_count - k < kChunk ? iso_count - k : kChunk;
+            rc = vr_render_device(c, view, iso_begin + k, n, 0, view->height, c->d_rgb + (size_t)k * frame_bytes,
+                                  (char *)c->d_stats + sizeof(vr_render_stats) * k, nullptr, c->stream);
+            if (rc != VR_OK) return rc;
+            hipEvent_t ev = c->chunk_done[n_chunk]; /* at most 4 chunks: iso_count <= 256 */
+            VR_HIP(hipEventRecord(ev, c->stream));
+            VR_HIP(hipStreamWaitEvent(c->copy_stream, ev, 0));
+            VR_HIP(hipMemcpyAsync(rgb24_out + (size_t)k * frame_bytes, c->d_rgb + (size_t)k * frame_bytes, frame_bytes * n,
+                                  hipMemcpyDeviceToHost, c->copy_stream));
+        }
+        if (stats_out)
+            VR_HIP(hipMemcpyAsync(stats_out, c->d_stats, sizeof(vr_render_stats) * iso_count, hipMemcpyDeviceToHost, c->stream));
+        VR_HIP(hipStreamSynchronize(c->stream));
+        VR_HIP(hipStreamSynchronize(c->copy_stream));
+        return VR_OK;
     }
     rc = vr_render_device(c, view, iso_begin, iso_count, 0, view->height, c->d_rgb, c->d_stats, &dt, c->stream);
     if (rc != VR_OK) return rc;
