@@ -55,6 +55,15 @@ pub extern fn vr_load_kdt(path: [*:0]const u8, nodes_out: *?[*]u32, n_slots_out:
 pub extern fn vr_mgpu_render_sweep(ctxs: [*]const ?*Ctx, n_ctx: u32, view: *const View, iso_begin: u32, iso_count: u32, shard: c_int, rgb24_out: [*]u8, stats_out: ?[*]RenderStats) c_int;
 pub extern fn vr_free(p: ?*anyopaque) void;
 pub extern fn vr_render(ctx: ?*Ctx, view: *const View, isoval: u8, rgb24_out: [*]u8, stats_out: ?*RenderStats, taps: ?*const anyopaque) c_int;
+/// rows [row_begin,row_end) of iso_count frames into DEVICE memory, asynchronous; `stream` is a hipStream_t
+/// (null = the context's own non-blocking stream: wait for it with vr_sync)
+pub extern fn vr_render_device(ctx: ?*Ctx, view: *const View, iso_begin: u32, iso_count: u32, row_begin: u32, row_end: u32, d_rgb24: ?*anyopaque, d_stats: ?*anyopaque, d_taps: ?*const anyopaque, stream: ?*anyopaque) c_int;
+pub extern fn vr_sync(ctx: ?*Ctx) c_int;
+/// page-locked frame buffers for vr_render / vr_render_sweep (full PCIe rate); release with vr_free_host
+pub extern fn vr_alloc_host(bytes: usize, out: *?*anyopaque) c_int;
+pub extern fn vr_free_host(p: ?*anyopaque) void;
+/// SlimKDT.newHeursiticPartition on the host (src/SlimKDT.zig:222-322); release nodes_out with vr_free
+pub extern fn vr_host_build_kdt(vox: [*]const u8, res: *const [3]u32, heuristic: c_int, max_slots: u64, nodes_out: *?[*]u32, n_slots_out: *u64, root_dim_out: *[3]u8, stats_out: ?*BuildStats) c_int;
 pub extern fn vr_render_sweep(ctx: ?*Ctx, view: *const View, iso_begin: u32, iso_count: u32, rgb24_out: [*]u8, stats_out: ?[*]RenderStats, taps: ?*const anyopaque) c_int;
 
 pub const Error = error{GpuRenderFailed};

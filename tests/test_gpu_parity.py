@@ -35,6 +35,23 @@ def skull_renderer(skull_tree):
     r.close()
 
 
+@pytest.fixture(scope="module")
+def standin_tree():
+    vox = vr.datasets.bonsai_standin()
+    return vox, vr.SlimKDT.newHeursiticPartition(vr.Data(vox), "AlwaysCenter")
+
+
+@pytest.fixture(scope="module")
+def standin_renderer(standin_tree):
+    """The 256^3 stand-in with its tree built on the GPU (word for word the host-built one:
+    test_gpu_tree_build_matches_host_builder)."""
+    r = vr.Renderer(0)
+    r.upload_volume(vr.Data(standin_tree[0]))
+    r.build_kdt("AlwaysCenter")
+    yield r
+    r.close()
+
+
 def _gpu(renderer, pos, forw, up, w, h, vp, iso):
     img = vr.Image(w, h)
     res = renderer.renderImage(pos, forw, up, img, vp, iso, taps=True)
@@ -395,6 +412,76 @@ def test_page_locked_output_buffer(oracle, c60_vox, c60_tree, c60_renderer):
     a = c60_renderer.renderSweep(pos, forw, up, 64, 40, 2.0, 97, 6, out=buf)
     b = c60_renderer.renderSweep(pos, forw, up, 64, 40, 2.0, 97, 6)
     assert a["rgb"] is buf and (buf == b["rgb"]).all() and buf.any()
+
+
+def test_page_locked_chunked_sweep_equals_pageable_and_reference_renders(oracle, c60_vox, c60_renderer, golden_gray):
+    """vr_render_sweep into page-locked memory goes in chunks of 64 iso values whose copies overlap the next
+    chunk's render (from 128 iso values and 32 MiB per chunk on).  C60 512^2: all 256 frames equal the
+    reference's renders and the pageable call (frames and counters); 130 iso values leave a 2-frame tail chunk,
+    which runs the one-traversal-per-iso kernel."""
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    for b, n in [(0, 256), (60, 130)]:
+        buf = c60_renderer.pinned_frames(n, 512, 512)
+        buf[...] = 7
+        a = c60_renderer.renderSweep(pos, forw, up, 512, 512, 2.0, b, n, out=buf)
+        p = c60_renderer.renderSweep(pos, forw, up, 512, 512, 2.0, b, n)
+        assert (a["rgb"][..., 0] == golden_gray[b:b + n]).all() and (a["rgb"] == p["rgb"]).all()
+        assert a["stats"] == p["stats"] and all(s["errors"] == 0 for s in a["stats"])
+        del a, buf
+
+
+def test_standin_256_cubed_sweep_kernel_every_iso_value_matches_oracle(oracle, standin_tree, standin_renderer):
+    """The 0..255 sweep of the 256^3 volume (depth-24 tree: 25 path-stack rows, 13 tree levels in LDS) through the
+    sweep kernel: every iso value against its own oracle render, all taps and counters."""
+    vox, k = standin_tree
+    pos, forw, up = oracle.main_camera(vox.shape)
+    standin_renderer.set_kernel(capi.KERNEL_SWEEP)
+    out = standin_renderer.renderSweep(pos, forw, up, 96, 80, 2.0, 0, 256, taps=True)
+    standin_renderer.set_kernel(capi.KERNEL_DEFAULT)
+    hits = 0
+    for j in range(256):
+        ref = oracle.render(k.nodes, k.root_dim, pos, forw, up, 96, 80, 2.0, j)
+        got = {"rgb": out["rgb"][j], "cell_flag": out["cell_flag"][j], "t": out["t"][j], "checked": out["checked"][j],
+               "node": out["node"][j], "stats": out["stats"][j]}
+        assert_same_render(got, ref, "stand-in sweep kernel iso %d" % j)
+        _check_stats(got, ref)
+        hits += ref["stats"].hit_count
+    assert hits > 100000
+
+
+def test_standin_256_cubed_full_size_sweep_equals_per_iso_kernel_and_iso_shards(oracle, standin_tree, standin_renderer):
+    """The 256^3 volume at 1024^2, iso 0..255: frames and all 7 counters of the sweep kernel equal those of the
+    one-traversal-per-iso kernel, and the 8 iso shards of an 8-GPU run, rendered one after the other, equal the
+    whole sweep."""
+    import torch
+    from volumerenderer_amd import sharding
+    vox, _ = standin_tree
+    pos, forw, up = oracle.main_camera(vox.shape)
+    L = capi.lib()
+    W = H = 1024
+    v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+
+    def run(b, n):
+        d_rgb = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+        d_stats = torch.zeros((n, 7), dtype=torch.int64, device="cuda")
+        capi.check(L.vr_render_device(standin_renderer.handle, C.byref(v), b, n, 0, H, d_rgb.data_ptr(), d_stats.data_ptr(),
+                                      None, None), "vr_render_device")
+        capi.check(L.vr_sync(standin_renderer.handle), "vr_sync")
+        return d_rgb, d_stats.cpu().numpy()
+
+    standin_renderer.set_kernel(capi.KERNEL_PIPELINE)
+    per_iso = run(0, 256)
+    standin_renderer.set_kernel(capi.KERNEL_SWEEP)
+    sweep = run(0, 256)
+    standin_renderer.set_kernel(capi.KERNEL_DEFAULT)
+    assert (per_iso[1] == sweep[1]).all() and int(sweep[1][:, 6].sum()) == 0 and int(sweep[1][:, 1].sum()) > 10 ** 7
+    assert bool(torch.equal(per_iso[0], sweep[0]))
+    del per_iso
+    for rank in range(8):
+        b, n = sharding.iso_shard(rank, 8)
+        part = run(b, n)
+        assert (part[1] == sweep[1][b:b + n]).all(), rank
+        assert bool(torch.equal(part[0], sweep[0][b:b + n])), rank
 
 
 def test_sweep_kernel_on_random_small_volumes(oracle):

@@ -155,6 +155,7 @@ int vr_ctx_create(int device, vr_ctx **out)
     c->device = device;
     c->n_cus = prop.multiProcessorCount;
     hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = vr_device_setup(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming);
@@ -461,23 +462,28 @@ int vr_render_sweep(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t
         else (void)hipGetLastError(); /* an ordinary heap pointer is "invalid value" to this query */
     }
     if (page_locked && !taps && iso_count >= 2 * kChunk && frame_bytes * kChunk >= ((size_t)32 << 20)) {
+        /* on any failure inside the loop the copies of earlier chunks may still be writing into the caller's
+         * buffer: both streams are drained before the error is returned */
         uint32_t n_chunk = 0;
-        for (uint32_t k = 0; k < iso_count; k += kChunk, n_chunk++) {
+        hipError_t e = hipSuccess;
+        rc = VR_OK;
+        for (uint32_t k = 0; k < iso_count && rc == VR_OK && e == hipSuccess; k += kChunk, n_chunk++) {
             const uint32_t n = iso_count - k < kChunk ? iso_count - k : kChunk;
             rc = vr_render_device(c, view, iso_begin + k, n, 0, view->height, c->d_rgb + (size_t)k * frame_bytes,
                                   (char *)c->d_stats + sizeof(vr_render_stats) * k, nullptr, c->stream);
-            if (rc != VR_OK) return rc;
+            if (rc != VR_OK) break;
             hipEvent_t ev = c->chunk_done[n_chunk]; /* at most 4 chunks: iso_count <= 256 */
-            VR_HIP(hipEventRecord(ev, c->stream));
-            VR_HIP(hipStreamWaitEvent(c->copy_stream, ev, 0));
-            VR_HIP(hipMemcpyAsync(rgb24_out + (size_t)k * frame_bytes, c->d_rgb + (size_t)k * frame_bytes, frame_bytes * n,
-                                  hipMemcpyDeviceToHost, c->copy_stream));
+            if ((e = hipEventRecord(ev, c->stream)) != hipSuccess) break;
+            if ((e = hipStreamWaitEvent(c->copy_stream, ev, 0)) != hipSuccess) break;
+            e = hipMemcpyAsync(rgb24_out + (size_t)k * frame_bytes, c->d_rgb + (size_t)k * frame_bytes, frame_bytes * n,
+                               hipMemcpyDeviceToHost, c->copy_stream);
         }
-        if (stats_out)
-            VR_HIP(hipMemcpyAsync(stats_out, c->d_stats, sizeof(vr_render_stats) * iso_count, hipMemcpyDeviceToHost, c->stream));
-        VR_HIP(hipStreamSynchronize(c->stream));
-        VR_HIP(hipStreamSynchronize(c->copy_stream));
-        return VR_OK;
+        if (rc == VR_OK && e == hipSuccess && stats_out)
+            e = hipMemcpyAsync(stats_out, c->d_stats, sizeof(vr_render_stats) * iso_count, hipMemcpyDeviceToHost, c->stream);
+        const hipError_t e1 = hipStreamSynchronize(c->stream), e2 = hipStreamSynchronize(c->copy_stream);
+        if (rc != VR_OK) return rc;
+        if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+        return e == hipSuccess ? VR_OK : VR_EHIP_BASE - (int)e;
     }
     rc = vr_render_device(c, view, iso_begin, iso_count, 0, view->height, c->d_rgb, c->d_stats, &dt, c->stream);
     if (rc != VR_OK) return rc;
@@ -514,40 +520,44 @@ int vr_mgpu_render_sweep(vr_ctx *const *ctxs, uint32_t n_ctx, const vr_view *vie
     const uint32_t total = shard == VR_SHARD_ISO ? iso_count : view->height;
     struct Part { uint32_t iso_b, iso_n, r0, r1; };
     Part part[64];
-    /* enqueue everything first, so that all devices work at the same time */
-    for (uint32_t i = 0; i < n_ctx; i++) {
+    /* enqueue everything first, so that all devices work at the same time; after a failure every context that has
+     * work in flight is drained before the error is returned (its copies write into the caller's buffers) */
+    auto step = [](hipError_t e) { return e == hipSuccess ? VR_OK : VR_EHIP_BASE - (int)e; };
+    uint32_t n_enqueued = 0;
+    rc = VR_OK;
+    for (uint32_t i = 0; i < n_ctx && rc == VR_OK; i++) {
         const uint32_t base = total / n_ctx, rem = total % n_ctx;
         const uint32_t begin = i * base + (i < rem ? i : rem), count = base + (i < rem ? 1u : 0u);
         Part &p = part[i];
         if (shard == VR_SHARD_ISO) { p.iso_b = iso_begin + begin; p.iso_n = count; p.r0 = 0; p.r1 = view->height; }
         else { p.iso_b = iso_begin; p.iso_n = iso_count; p.r0 = begin; p.r1 = begin + count; }
+        n_enqueued = i + 1u;
         if (count == 0) continue; /* more contexts than frames / rows */
         vr_ctx *c = ctxs[i];
-        VR_HIP(hipSetDevice(c->device));
         const size_t part_frame = row_bytes * (p.r1 - p.r0);
-        rc = ensure((void **)&c->d_rgb, &c->rgb_cap, part_frame * p.iso_n);
-        if (rc != VR_OK) return rc;
-        rc = ensure((void **)&c->d_stats, &c->stats_cap, sizeof(vr_render_stats) * p.iso_n);
-        if (rc != VR_OK) return rc;
-        rc = vr_render_device(c, view, p.iso_b, p.iso_n, p.r0, p.r1, c->d_rgb, c->d_stats, nullptr, c->stream);
-        if (rc != VR_OK) return rc;
+        if ((rc = step(hipSetDevice(c->device))) != VR_OK) break;
+        if ((rc = ensure((void **)&c->d_rgb, &c->rgb_cap, part_frame * p.iso_n)) != VR_OK) break;
+        if ((rc = ensure((void **)&c->d_stats, &c->stats_cap, sizeof(vr_render_stats) * p.iso_n)) != VR_OK) break;
+        if ((rc = vr_render_device(c, view, p.iso_b, p.iso_n, p.r0, p.r1, c->d_rgb, c->d_stats, nullptr, c->stream)) != VR_OK) break;
         /* frame k of the part: rows [r0, r1) of frame (iso_b - iso_begin + k) of the output */
         uint8_t *dst = rgb24_out + (size_t)(p.iso_b - iso_begin) * frame_bytes + (size_t)p.r0 * row_bytes;
-        VR_HIP(hipMemcpy2DAsync(dst, frame_bytes, c->d_rgb, part_frame, part_frame, p.iso_n, hipMemcpyDeviceToHost, c->stream));
+        rc = step(hipMemcpy2DAsync(dst, frame_bytes, c->d_rgb, part_frame, part_frame, p.iso_n, hipMemcpyDeviceToHost, c->stream));
     }
     if (stats_out) std::memset(stats_out, 0, sizeof(vr_render_stats) * iso_count);
     std::vector<vr_render_stats> tmp;
-    for (uint32_t i = 0; i < n_ctx; i++) {
+    for (uint32_t i = 0; i < n_enqueued; i++) {
         const Part &p = part[i];
         if ((shard == VR_SHARD_ISO ? p.iso_n : p.r1 - p.r0) == 0) continue;
         vr_ctx *c = ctxs[i];
-        VR_HIP(hipSetDevice(c->device));
-        if (stats_out) {
+        int rc_i = step(hipSetDevice(c->device));
+        if (rc_i == VR_OK && rc == VR_OK && stats_out) {
             tmp.resize(p.iso_n);
-            VR_HIP(hipMemcpyAsync(tmp.data(), c->d_stats, sizeof(vr_render_stats) * p.iso_n, hipMemcpyDeviceToHost, c->stream));
+            rc_i = step(hipMemcpyAsync(tmp.data(), c->d_stats, sizeof(vr_render_stats) * p.iso_n, hipMemcpyDeviceToHost, c->stream));
         }
-        VR_HIP(hipStreamSynchronize(c->stream));
-        if (stats_out)
+        const int rc_s = step(hipStreamSynchronize(c->stream)); /* always: nothing of this call stays in flight */
+        if (rc_i == VR_OK) rc_i = rc_s;
+        if (rc == VR_OK) rc = rc_i;
+        if (rc == VR_OK && stats_out)
             for (uint32_t k = 0; k < p.iso_n; k++) {
                 vr_render_stats &o = stats_out[p.iso_b - iso_begin + k];
                 const vr_render_stats &s = tmp[k];
@@ -556,7 +566,7 @@ int vr_mgpu_render_sweep(vr_ctx *const *ctxs, uint32_t n_ctx, const vr_view *vie
                 o.errors += s.errors;
             }
     }
-    return VR_OK;
+    return rc;
 }
 
 int vr_sync(vr_ctx *c)

@@ -39,6 +39,10 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
                             const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end);
 
+/* Once per device, with that device current (vr_ctx_create calls it; safe from several threads): raises the
+ * dynamic-LDS ceiling of the persistent kernels, which is a property of the function on the device. */
+hipError_t vr_device_setup(int device);
+
 /* GPU build of the centre-split tree (vr_build.hip): depth of the deepest leaf for a volume of rx x ry x rz
  * voxels, and the two passes that fill 2^(depth+1) raw slots and 2^(depth+1) + 1 prepared words. */
 uint32_t vr_center_tree_depth(uint32_t rx, uint32_t ry, uint32_t rz);

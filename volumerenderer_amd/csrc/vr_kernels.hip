@@ -27,6 +27,7 @@
  */
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 #include "vr_internal.h"
 #include "vr_trace_wide.h"
@@ -1080,21 +1081,30 @@ hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_
     return hipGetLastError();
 }
 
-/* the dynamic-LDS ceiling is a property of the function on the current device: raised once per device and kernel */
-hipError_t allow_full_lds(const void *fn, int fn_id)
+} // namespace
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_setup_mutex;
+bool g_setup_done[kMaxDevices];
+} // namespace
+
+/* Once per device, with that device current (called by vr_ctx_create): raises the dynamic-LDS ceiling of the
+ * persistent kernels (a property of the function on the device). */
+hipError_t vr_device_setup(int device)
 {
-    static bool lds_set[64][6];
-    int dev = 0;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_setup_mutex);
+    if (g_setup_done[device]) return hipSuccess;
     hipError_t e;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !lds_set[dev][fn_id]) {
+    const void *fns[] = { (const void *)vr_k_trace<false>,      (const void *)vr_k_trace<true>,
+                          (const void *)vr_k_sweep<false>,      (const void *)vr_k_sweep<true>,
+                          (const void *)vr_k_trace_wide<false>, (const void *)vr_k_trace_wide<true> };
+    for (const void *fn : fns)
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u))) != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) lds_set[dev][fn_id] = true;
-    }
+    g_setup_done[device] = true;
     return hipSuccess;
 }
-
-} // namespace
 
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count)
 {
@@ -1177,10 +1187,8 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     const uint32_t n_top = 1u << top_levels; /* heap positions 0 .. 2^K - 1 = levels 0 .. K-1 (K = 0: the unused slot 0 only) */
     const size_t trace_lds = (size_t)n_top * sizeof(uint32_t) + trace_stack_bytes + stat_bytes;
     if (trace_lds > lds_limit) return hipErrorInvalidValue;
-    const int fn_id = (sweep ? 2 : 0) + (any_tap ? 1 : 0);
     const void *fn = sweep ? (any_tap ? (const void *)vr_k_sweep<true> : (const void *)vr_k_sweep<false>)
                            : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
-    if ((e = allow_full_lds(fn, fn_id)) != hipSuccess) return e;
     const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
     const uint64_t frame_pixels = n_pix;
     const uint32_t stack_rows = stack_levels + 1u;
@@ -1264,7 +1272,6 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         return e;
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
     const void *fn = any_tap ? (const void *)vr_k_trace_wide<true> : (const void *)vr_k_trace_wide<false>;
-    if ((e = allow_full_lds(fn, 4 + (any_tap ? 1 : 0))) != hipSuccess) return e;
     const size_t lds = (size_t)VR_WIDE_MAX_DEPTH * kWideThreads * sizeof(uint32_t);
     const uint32_t blocks = (uint32_t)n_cus * kWideBlocksPerCu;
     const uint64_t frame_pixels = (uint64_t)view.width * n_rows;

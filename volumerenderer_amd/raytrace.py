@@ -45,15 +45,11 @@ class Renderer:
         self._ctx = C.c_void_p()
         capi.check(self._L.vr_ctx_create(int(device), C.byref(self._ctx)), "vr_ctx_create")
         self.kdt = None
-        self._pinned = []
 
     def close(self):
         if self._ctx:
             self._L.vr_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
-        for _, p in getattr(self, "_pinned", []):
-            self._L.vr_free_host(p)
-        self._pinned = []
 
     def __enter__(self):
         return self
@@ -115,15 +111,16 @@ class Renderer:
         return nodes, np.array(list(rd), dtype=np.uint16), n.value
 
     def pinned_frames(self, iso_count, height, width):
-        """uint8[iso_count, height, width, 3] in page-locked host memory (vr_alloc_host); the array keeps the
-        allocation alive and releases it when it is collected."""
+        """uint8[iso_count, height, width, 3] in page-locked host memory (vr_alloc_host).  The allocation belongs
+        to the returned array, not to the Renderer: it is released (vr_free_host) when the last view of the array
+        has been collected, so frames stay readable after close()."""
+        import weakref
         n = int(iso_count) * int(height) * int(width) * 3
         p = C.c_void_p()
         capi.check(self._L.vr_alloc_host(n, C.byref(p)), "vr_alloc_host")
-        buf = (C.c_uint8 * n).from_address(p.value)
-        arr = np.frombuffer(buf, dtype=np.uint8).reshape(iso_count, height, width, 3)
-        self._pinned.append((arr, p))
-        return arr
+        buf = (C.c_uint8 * n).from_address(p.value)  # every numpy view keeps `buf` alive through .base
+        weakref.finalize(buf, self._L.vr_free_host, C.c_void_p(p.value))
+        return np.frombuffer(buf, dtype=np.uint8).reshape(iso_count, height, width, 3)
 
     def renderSweep(self, src, forw, up, width, height, viewport_width, iso_begin, iso_count, taps=False, out=None):
         """iso loop of src/main.zig:111-138.  Returns dict(rgb[iso,h,w,3], stats[list], + taps).  `out`: frames
