@@ -58,6 +58,8 @@ pub extern fn vr_render(ctx: ?*Ctx, view: *const View, isoval: u8, rgb24_out: [*
 /// rows [row_begin,row_end) of iso_count frames into DEVICE memory, asynchronous; `stream` is a hipStream_t
 /// (null = the context's own non-blocking stream: wait for it with vr_sync)
 pub extern fn vr_render_device(ctx: ?*Ctx, view: *const View, iso_begin: u32, iso_count: u32, row_begin: u32, row_end: u32, d_rgb24: ?*anyopaque, d_stats: ?*anyopaque, d_taps: ?*const anyopaque, stream: ?*anyopaque) c_int;
+/// the same call with its scratch in a static device array: no allocation inside, at most 2^20 pixels per call
+pub extern fn vr_render_device_noalloc(ctx: ?*Ctx, view: *const View, iso_begin: u32, iso_count: u32, row_begin: u32, row_end: u32, d_rgb24: ?*anyopaque, d_stats: ?*anyopaque, d_taps: ?*const anyopaque, stream: ?*anyopaque) c_int;
 pub extern fn vr_sync(ctx: ?*Ctx) c_int;
 /// page-locked frame buffers for vr_render / vr_render_sweep (full PCIe rate); release with vr_free_host
 pub extern fn vr_alloc_host(bytes: usize, out: *?*anyopaque) c_int;

@@ -36,6 +36,7 @@ extern "C" {
 #define VR_ENODEVICE (-7) /* no usable HIP device / the device is not gfx950                      */
 #define VR_ETREE (-8)     /* uploaded tree is malformed: a reachable node lies outside the array,  */
                           /* or an inner node's partition is not strictly inside its box          */
+#define VR_ELIMIT (-9)    /* the call is beyond a fixed limit of the entry point (vr_render_device_noalloc)  */
 #define VR_EHIP_BASE (-1000) /* VR_EHIP_BASE - hipError_t                                         */
 
 /* Per-pixel flag stored in bits 24..31 of a cell/flag tap word. */
@@ -241,6 +242,21 @@ int vr_render_sweep(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint32
 int vr_render_device(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint32_t iso_count,
                      uint32_t row_begin, uint32_t row_end, void *d_rgb24, void *d_stats,
                      const vr_taps *d_taps, void *stream);
+
+/* vr_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference (its renderImage allocates nothing
+ * either, src/raytrace.zig:11-106, but runs on the CPU).  Same arguments, same results as vr_render_device, but
+ * the scratch of the pipeline kernels (ray list, tile offsets, queue heads) is a static device array of 24 MiB
+ * per GPU instead of a buffer the context grows on demand, and the call makes no hipMalloc / hipFree and creates
+ * no events (the kernel-time probe of vr_set_timing does not cover it).
+ * Limit: (row_end - row_begin) * width <= 2^20 pixels per call (e.g. one 1024 x 1024 frame range; render larger
+ * frames in row bands); beyond it VR_ELIMIT.  Any number of iso values.
+ * All contexts on one GPU share the one array: calls of this entry point that overlap in time on one GPU (two
+ * streams, two contexts, two threads) race on it and must be serialised by the caller; it does not touch the
+ * scratch of vr_render_device, so a call may overlap with calls of the other entry points. */
+int vr_render_device_noalloc(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint32_t iso_count,
+                             uint32_t row_begin, uint32_t row_end, void *d_rgb24, void *d_stats,
+                             const vr_taps *d_taps, void *stream);
 
 /* One host thread driving several contexts -- normally one per GPU of the node, each holding the same tree
  * (contexts on one device work too).  The iso loop of src/main.zig:111-138 is split over the contexts with no

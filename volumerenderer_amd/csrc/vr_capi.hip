@@ -372,8 +372,12 @@ int vr_download_kdt_wide(vr_ctx *c, uint32_t *nodes_out, uint64_t first_slot, ui
     return VR_OK;
 }
 
-int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
-                     uint32_t row_end, void *d_rgb24, void *d_stats, const vr_taps *d_taps, void *stream)
+/* Shared body of the two device-resident entry points.  `fixed_scratch` = null: the context's own workspace,
+ * grown on demand (the only allocation on that path).  Otherwise the pipeline runs in `fixed_scratch`
+ * (fixed_bytes long) and nothing is allocated or created. */
+static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
+                         uint32_t row_end, void *d_rgb24, void *d_stats, const vr_taps *d_taps, void *stream,
+                         void *fixed_scratch, size_t fixed_bytes)
 {
     if (!c || !d_rgb24) return VR_EARG;
     int rc = check_view(view);
@@ -393,16 +397,25 @@ int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_
     }
     const int variant = c->variant;
     const bool per_pixel = variant == VR_KERNEL_RESTART_GLOBAL || variant == VR_KERNEL_RESTART_LDS || variant == VR_KERNEL_RESUME;
-    if (!per_pixel) {
-        /* growing the scratch is the only allocation on this path; it happens when a larger view comes */
-        const size_t need = vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count);
-        if (need > c->work_cap) VR_HIP(hipStreamSynchronize(s));
-        rc = ensure(&c->d_work, &c->work_cap, need);
-        if (rc != VR_OK) return rc;
+    void *work = nullptr;
+    if (fixed_scratch) {
+        if ((size_t)view->width * (row_end - row_begin) > VR_NOALLOC_MAX_PIXELS) return VR_ELIMIT;
+        if (vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count) > fixed_bytes) return VR_ELIMIT;
+        work = fixed_scratch;
+    } else {
+        if (!per_pixel) {
+            /* growing the scratch is the only allocation on this path; it happens when a larger view comes */
+            const size_t need = vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count);
+            if (need > c->work_cap) VR_HIP(hipStreamSynchronize(s));
+            rc = ensure(&c->d_work, &c->work_cap, need);
+            if (rc != VR_OK) return rc;
+        }
+        work = c->d_work;
     }
     if (d_stats) VR_HIP(hipMemsetAsync(d_stats, 0, sizeof(vr_render_stats) * iso_count, s));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (c->timing) {
+    const bool timing = c->timing && !fixed_scratch; /* the probe may have to create events */
+    if (timing) {
         while (c->ev.size() < c->ev_used + 2) {
             hipEvent_t e;
             VR_HIP(hipEventCreate(&e));
@@ -413,12 +426,28 @@ int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_
     }
     if (c->wide)
         VR_HIP(vr_launch_render_wide(variant, s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
-                                     (vr_render_stats *)d_stats, taps, c->d_work, c->n_cus, ev0, ev1));
+                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1));
     else
         VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
-                                row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, c->d_work, c->n_cus, ev0, ev1));
-    if (c->timing) c->ev_used += 2;
+                                row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1));
+    if (timing) c->ev_used += 2;
     return VR_OK;
+}
+
+int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
+                     uint32_t row_end, void *d_rgb24, void *d_stats, const vr_taps *d_taps, void *stream)
+{
+    return render_device(c, view, iso_begin, iso_count, row_begin, row_end, d_rgb24, d_stats, d_taps, stream, nullptr, 0);
+}
+
+int vr_render_device_noalloc(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
+                             uint32_t row_end, void *d_rgb24, void *d_stats, const vr_taps *d_taps, void *stream)
+{
+    if (!c) return VR_EARG;
+    void *fixed = vr_noalloc_scratch(c->device); /* looked up by vr_ctx_create on this device */
+    if (!fixed) return VR_ESTATE;
+    return render_device(c, view, iso_begin, iso_count, row_begin, row_end, d_rgb24, d_stats, d_taps, stream, fixed,
+                         VR_NOALLOC_SCRATCH_BYTES);
 }
 
 int vr_render_sweep(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint8_t *rgb24_out,

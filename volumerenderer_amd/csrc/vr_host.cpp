@@ -205,6 +205,7 @@ const char *vr_strerror(int code)
     case VR_EIO: return "cannot read file";
     case VR_EFORMAT: return "malformed .vol file";
     case VR_ENODEVICE: return "no gfx950 HIP device";
+    case VR_ELIMIT: return "beyond a fixed limit of the entry point";
     case VR_ETREE: return "malformed tree (a reachable node lies outside the array or does not split its box)";
     default: return code <= VR_EHIP_BASE ? "HIP runtime error (code = VR_EHIP_BASE - hipError_t)" : "unknown error";
     }

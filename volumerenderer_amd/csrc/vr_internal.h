@@ -40,8 +40,17 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                             const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end);
 
 /* Once per device, with that device current (vr_ctx_create calls it; safe from several threads): raises the
- * dynamic-LDS ceiling of the persistent kernels, which is a property of the function on the device. */
+ * dynamic-LDS ceiling of the persistent kernels, which is a property of the function on the device, and looks
+ * up the address of this GPU's copy of the static scratch array. */
 hipError_t vr_device_setup(int device);
+
+/* The static scratch array of vr_render_device_noalloc: VR_NOALLOC_SCRATCH_BYTES bytes per GPU, enough for the
+ * pipeline workspace of any view of up to VR_NOALLOC_MAX_PIXELS pixels (20 B per pixel for the ray list, up to
+ * 2 MiB of tile offsets for one-pixel-wide views, 256 queue heads).  vr_noalloc_scratch returns the device
+ * address on `device` (null before vr_device_setup ran there). */
+#define VR_NOALLOC_MAX_PIXELS ((size_t)1 << 20)
+#define VR_NOALLOC_SCRATCH_BYTES ((size_t)24 << 20)
+void *vr_noalloc_scratch(int device);
 
 /* GPU build of the centre-split tree (vr_build.hip): depth of the deepest leaf for a volume of rx x ry x rz
  * voxels, and the two passes that fill 2^(depth+1) raw slots and 2^(depth+1) + 1 prepared words. */

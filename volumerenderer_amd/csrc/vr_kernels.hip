@@ -1083,14 +1083,22 @@ hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_
 
 } // namespace
 
+/* Scratch of the entry point that allocates nothing (vr_render_device_noalloc): the ray list, tile offsets, ray
+ * count and queue heads of one call.  Every GPU the library runs on holds its own copy until the process ends,
+ * and every call on a GPU shares that copy.  In host code this name is a stand-in, not a device address: the
+ * address comes from hipGetSymbolAddress, once per device (vr_device_setup), and only that pointer is handed to
+ * kernels and memsets. */
+static __device__ __align__(256) unsigned char scratch[VR_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_setup_mutex;
 bool g_setup_done[kMaxDevices];
+void *g_scratch_ptr[kMaxDevices]; /* device address of `scratch` on each GPU */
 } // namespace
 
 /* Once per device, with that device current (called by vr_ctx_create): raises the dynamic-LDS ceiling of the
- * persistent kernels (a property of the function on the device). */
+ * persistent kernels (a property of the function on the device) and looks up this GPU's copy of `scratch`. */
 hipError_t vr_device_setup(int device)
 {
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
@@ -1102,8 +1110,19 @@ hipError_t vr_device_setup(int device)
                           (const void *)vr_k_trace_wide<false>, (const void *)vr_k_trace_wide<true> };
     for (const void *fn : fns)
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u))) != hipSuccess) return e;
+    void *p = nullptr;
+    if ((e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch))) != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = p;
     g_setup_done[device] = true;
     return hipSuccess;
+}
+
+void *vr_noalloc_scratch(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_setup_mutex);
+    return g_setup_done[device] ? g_scratch_ptr[device] : nullptr;
 }
 
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count)
