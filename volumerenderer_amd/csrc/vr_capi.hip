@@ -412,7 +412,6 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         }
         work = c->d_work;
     }
-    if (d_stats) VR_HIP(hipMemsetAsync(d_stats, 0, sizeof(vr_render_stats) * iso_count, s));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool timing = c->timing && !fixed_scratch; /* the probe may have to create events */
     if (timing) {

@@ -239,72 +239,108 @@ __device__ __forceinline__ bool tile_ray(const VrViewK &v, uint32_t tile, uint32
     return !ray.oob;
 }
 
-/* 1a: number of rays per tile that enter the root box */
-__global__ __launch_bounds__(256) void vr_k_count(VrViewK v, uint32_t row_begin, uint32_t n_rows, uint32_t n_tiles, uint32_t center_out,
-                                                  uint32_t *__restrict__ tile_count)
+/* The pre-pass works in blocks of one super-tile (kSuper x kSuper tiles, one wave per tile): what a block adds
+ * to the ray list is contiguous there, and only one number per block goes through the scan. */
+constexpr uint32_t kPreThreads = kSuper * kSuper * 64u;
+static_assert(kPreThreads <= 1024u, "a super-tile must fit one block");
+
+/* entry test of the block's tiles; returns the number of entering rays in the tiles before this wave's tile
+ * (exclusive prefix inside the block) and the block total */
+__device__ __forceinline__ bool pre_block(const VrViewK &v, uint32_t row_begin, uint32_t n_rows, bool center_out, VrRay &ray,
+                                          uint32_t &pix, unsigned long long &mask, uint32_t &before, uint32_t &total)
 {
-    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (tile >= n_tiles) return;
-    VrRay ray;
-    uint32_t pix;
-    const bool active = tile_ray(v, tile, lane, row_begin, n_rows, center_out != 0u, ray, pix);
-    const unsigned long long m = __ballot(active);
-    if (lane == 0) tile_count[tile] = (uint32_t)__popcll(m);
+    __shared__ uint32_t s_cnt[kSuper * kSuper];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * (kSuper * kSuper) + wave;
+    const bool active = tile_ray(v, tile, lane, row_begin, n_rows, center_out, ray, pix);
+    mask = __ballot(active);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    before = 0; total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kSuper * kSuper; w++) {
+        const uint32_t c = s_cnt[w];
+        before += w < wave ? c : 0u;
+        total += c;
+    }
+    return active;
 }
 
-/* 1b: exclusive scan of the tile counts in place, by one block; writes the total */
-__global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ tile_count, uint32_t n_tiles,
-                                                  uint32_t *__restrict__ n_active_out)
+/* 1a: number of rays per super-tile that enter the root box */
+__global__ __launch_bounds__(kPreThreads) void vr_k_count(VrViewK v, uint32_t row_begin, uint32_t n_rows, uint32_t center_out,
+                                                          uint32_t *__restrict__ block_count)
 {
-    __shared__ uint32_t s_part[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n_tiles + 1023u) / 1024u;
-    const uint32_t b = tid * per, e = b + per < n_tiles ? b + per : n_tiles;
+    VrRay ray;
+    uint32_t pix, before, total;
+    unsigned long long mask;
+    (void)pre_block(v, row_begin, n_rows, center_out != 0u, ray, pix, mask, before, total);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+
+/* 1b: exclusive scan of the per-block counts in place, by one block; writes the total.  Every wave takes a
+ * contiguous share and goes through it 64 values at a time (coalesced), twice: totals first, then the scan. */
+__global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, uint32_t n, uint32_t *__restrict__ n_active_out,
+                                                  uint32_t *__restrict__ heads, uint32_t iso_count,
+                                                  vr_render_stats *__restrict__ stats, uint64_t frame_pixels)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t per = ((n + 15u) / 16u + 63u) & ~63u; /* values per wave, a multiple of 64 */
+    const uint32_t b = wave * per, e = b + per < n ? b + per : n;
     uint32_t sum = 0;
-    for (uint32_t i = b; i < e; i++) sum += tile_count[i];
-    s_part[tid] = sum;
+    for (uint32_t i = b + lane; i < e; i += 64u) sum += count[i];
+    sum = wave_sum(sum);
+    if (lane == 0) s_wave[wave] = sum;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) { /* Hillis-Steele inclusive scan of the partials */
-        uint32_t x = tid >= off ? s_part[tid - off] : 0u;
-        __syncthreads();
-        s_part[tid] += x;
-        __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16u; w++) {
+        const uint32_t c = s_wave[w];
+        run += w < wave ? c : 0u;
+        total += c;
     }
-    uint32_t run = s_part[tid] - sum;
-    for (uint32_t i = b; i < e; i++) {
-        const uint32_t c = tile_count[i];
-        tile_count[i] = run;
-        run += c;
+    for (uint32_t i0 = b; i0 < e; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const uint32_t c = i < e ? count[i] : 0u;
+        uint32_t x = c; /* inclusive scan over the wave */
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off, 64);
+            x += lane >= (uint32_t)off ? y : 0u;
+        }
+        if (i < e) count[i] = run + x - c;
+        run += __shfl(x, 63, 64);
     }
-    if (tid == 1023u) *n_active_out = s_part[1023];
+    if (threadIdx.x == 0) *n_active_out = total;
+    /* the small set-up work of a call rides along: empty queues, and the per-iso counters at their starting
+     * values (every pixel that never enters the volume is OOB in every frame) */
+    for (uint32_t k = threadIdx.x; k < iso_count; k += 1024u) {
+        heads[k] = 0u;
+        if (stats) {
+            vr_render_stats z = { 0, 0, 0, frame_pixels - total, 0, 0, 0 };
+            stats[k] = z;
+        }
+    }
 }
 
 /* 1c: dense ray list in tile order: (dx, dy, dz, entry t) and the pixel index inside one frame */
-__global__ __launch_bounds__(256) void vr_k_compact(VrViewK v, uint32_t row_begin, uint32_t n_rows, uint32_t n_tiles, uint32_t center_out,
-                                                    const uint32_t *__restrict__ tile_off, float4 *__restrict__ ray_dt,
-                                                    uint32_t *__restrict__ ray_pix)
+__global__ __launch_bounds__(kPreThreads) void vr_k_compact(VrViewK v, uint32_t row_begin, uint32_t n_rows, uint32_t center_out,
+                                                            const uint32_t *__restrict__ block_off, float4 *__restrict__ ray_dt,
+                                                            uint32_t *__restrict__ ray_pix)
 {
-    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (tile >= n_tiles) return;
     VrRay ray;
-    uint32_t pix;
-    const bool active = tile_ray(v, tile, lane, row_begin, n_rows, center_out != 0u, ray, pix);
-    const unsigned long long m = __ballot(active);
+    uint32_t pix, before, total;
+    unsigned long long mask;
+    const bool active = pre_block(v, row_begin, n_rows, center_out != 0u, ray, pix, mask, before, total);
     if (active) {
-        const uint32_t slot = tile_off[tile] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t slot = block_off[blockIdx.x] + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         ray_dt[slot] = make_float4(ray.dx, ray.dy, ray.dz, ray.t);
         ray_pix[slot] = pix;
     }
 }
 
-/* every pixel that never enters the volume is OOB in every frame: per-frame count, and tap defaults */
-__global__ void vr_k_oob_stats(vr_render_stats *__restrict__ stats, uint32_t iso_count, uint64_t frame_pixels,
-                               const uint32_t *__restrict__ n_active)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < iso_count) stats[k].oob_count = frame_pixels - *n_active;
-}
-
+/* taps of the pixels no ray list entry writes */
 __global__ void vr_k_tap_defaults(VrTapsK taps, uint64_t n, uint32_t oob_word)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -346,6 +382,121 @@ constexpr uint32_t kTraceThreads = VR_TRACE_THREADS;
 constexpr uint32_t kTraceBlocksPerCu = VR_TRACE_BLOCKS_PER_CU;
 constexpr uint32_t kTraceWavesPerSimd = kTraceThreads / 64u * kTraceBlocksPerCu / 4u;
 
+/* Per-iso counters of the kernels with one traversal per iso value.  With a handful of iso values every wave of
+ * the grid would add to the same few words, and device-wide atomics on one address are served in series (about
+ * 10 ns each: the backlog of 4096 waves x 6 counters outlasts a short kernel).  There each wave stores its sums
+ * in a slot of its own (`slots`: [iso][wave] records) and vr_k_sum_slots adds them up afterwards; sweeps of many
+ * iso values spread over as many records and use atomics. */
+constexpr uint32_t kSlotIsoMax = 8, kSlotWaveMax = 8192;
+struct WaveStats { unsigned long long checked; uint32_t hit, miss, esc, moves, err, pad; };
+
+__device__ __forceinline__ void wave_stats_out(vr_render_stats *__restrict__ stats, WaveStats *__restrict__ slots, uint32_t k,
+                                               uint32_t gw, uint32_t n_waves, uint32_t lane, unsigned long long a_checked,
+                                               uint32_t a_hit, uint32_t a_miss, uint32_t a_esc, uint32_t a_moves, uint32_t a_err)
+{
+    const unsigned long long c_checked = wave_sum64(a_checked);
+    const uint32_t c_hit = wave_sum(a_hit), c_miss = wave_sum(a_miss), c_moves = wave_sum(a_moves);
+    const uint32_t c_esc = wave_sum(a_esc), c_err = wave_sum(a_err);
+    if (lane != 0) return;
+    if (slots) {
+        WaveStats w = { c_checked, c_hit, c_miss, c_esc, c_moves, c_err, 0u };
+        slots[(size_t)k * n_waves + gw] = w;
+        return;
+    }
+    vr_render_stats *s = stats + k;
+    add_stat(&s->nodes_checked, c_checked);
+    add_stat(&s->hit_count, c_hit);
+    add_stat(&s->miss_count, c_miss);
+    add_stat(&s->escape_help_events, c_esc);
+    add_stat(&s->moves, c_moves);
+    add_stat(&s->errors, c_err);
+}
+
+/* one block per iso value: the sums of the waves' slots become the counters (oob_count was set by the scan kernel) */
+__global__ __launch_bounds__(1024) void vr_k_sum_slots(const WaveStats *__restrict__ slots, uint32_t n_waves,
+                                                       vr_render_stats *__restrict__ stats)
+{
+    __shared__ unsigned long long s_part[16][6];
+    const uint32_t k = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    unsigned long long a[6] = { 0, 0, 0, 0, 0, 0 };
+    for (uint32_t w = threadIdx.x; w < n_waves; w += 1024u) {
+        const WaveStats x = slots[(size_t)k * n_waves + w];
+        a[0] += x.checked; a[1] += x.hit; a[2] += x.miss; a[3] += x.esc; a[4] += x.moves; a[5] += x.err;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        a[i] = wave_sum64(a[i]);
+        if (lane == 0) s_part[wave][i] = a[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned long long t = 0;
+        for (uint32_t w = 0; w < 16u; w++) t += s_part[w][threadIdx.x];
+        vr_render_stats *s = stats + k;
+        uint64_t *dst = threadIdx.x == 0 ? &s->nodes_checked : threadIdx.x == 1 ? &s->hit_count : threadIdx.x == 2 ? &s->miss_count
+                      : threadIdx.x == 3 ? &s->escape_help_events : threadIdx.x == 4 ? &s->moves : &s->errors;
+        *dst = t;
+    }
+}
+
+/* A wave's private share of a work queue.  Waves take work from the shared queue head in chunks and hand it
+ * to their idle lanes from there, so the head sees one atomic per chunk instead of one per refill (a device-wide
+ * atomic on one address is served in series: with a single iso value every wave of the grid pulls from the same
+ * head: 10 ns per atomic, measured).  Chunks stay small -- neighbouring chunks go to waves that run at the same
+ * time, which is what keeps the node lines they share hot in the L1 / L2; large private chunks send every wave
+ * to a region of its own and lose more than the atomics cost.  The sweep kernel's items are long and few, its
+ * head is far from saturated, and items kept back by one wave are missed by the others at the end of the queue:
+ * there a wave takes exactly what its idle lanes need (measured: 4.3 ms against 4.7 - 6.7 ms with chunks of 16 - 128). */
+#ifndef VR_TRACE_CHUNK_MAX
+#define VR_TRACE_CHUNK_MAX 128
+#endif
+#ifndef VR_SWEEP_CHUNK
+#define VR_SWEEP_CHUNK 0 /* items per chunk of the sweep kernel; 0 = exactly what the idle lanes need, nothing kept back */
+#endif
+/* rays per chunk of the kernels with one traversal per iso value: one wave's worth, more (up to
+ * VR_TRACE_CHUNK_MAX) when there are many rays per wave of the grid, as in a 4096^2 frame */
+__device__ __forceinline__ uint32_t trace_chunk(uint32_t n_active, uint32_t n_waves)
+{
+    uint32_t c = 64u;
+    while (c < VR_TRACE_CHUNK_MAX && (uint64_t)c * 16u * n_waves <= n_active) c <<= 1;
+    return c;
+}
+struct WaveChunk {
+    uint32_t next, end; /* uniform over the wave */
+    bool dry;           /* the shared queue has nothing left */
+    __device__ __forceinline__ WaveChunk() : next(0), end(0), dry(false) {}
+    __device__ __forceinline__ void grab(uint32_t *head, uint32_t n_total, uint32_t want, uint32_t lane)
+    {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(head, want);
+        base = __builtin_amdgcn_readfirstlane(base);
+        dry = base >= n_total;
+        next = dry ? 0u : base;
+        end = dry ? 0u : (base + want < n_total ? base + want : n_total);
+    }
+    /* Work for the n_idle idle lanes of the wave (`rank` = this lane's position among them): true and the item
+     * in `mine` for the lanes that get one.  Takes what the wave's chunk still holds and, when that is not
+     * enough, the rest from one fresh chunk. */
+    __device__ __forceinline__ bool take(uint32_t n_idle, uint32_t rank, uint32_t *head, uint32_t n_total, uint32_t want,
+                                         uint32_t lane, uint32_t &mine)
+    {
+        if (next >= end && !dry) grab(head, n_total, want, lane);
+        const uint32_t base1 = next, have1 = end - next, take1 = n_idle < have1 ? n_idle : have1;
+        next += take1;
+        uint32_t base2 = 0, take2 = 0;
+        if (take1 < n_idle && !dry) {
+            grab(head, n_total, want, lane);
+            const uint32_t have2 = end - next;
+            base2 = next;
+            take2 = n_idle - take1 < have2 ? n_idle - take1 : have2;
+            next += take2;
+        }
+        mine = rank < take1 ? base1 + rank : base2 + (rank - take1);
+        return rank < take1 + take2;
+    }
+    __device__ __forceinline__ bool exhausted() const { return dry && next >= end; }
+};
+
 template <bool TAPS>
 __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top,
                                                             uint32_t stack_rows,
@@ -355,7 +506,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
                                                             uint32_t *__restrict__ heads, uint32_t iso_begin,
                                                             uint32_t iso_count, uint64_t frame_pixels,
                                                             uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
-                                                            VrTapsK taps)
+                                                            WaveStats *__restrict__ slots, VrTapsK taps)
 {
     /* dynamic LDS: [path stacks: stack_rows x kTraceThreads words][n_top node words: heap positions 0 .. n_top-1] */
     extern __shared__ uint32_t s_dyn[];
@@ -372,6 +523,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
     /* spread the waves over the iso queues; each wave then walks all queues cyclically, so waves that
      * run out of work on a cheap iso value move on to help with the expensive ones */
     const uint32_t k0 = (uint32_t)(((uint64_t)gw * iso_count) / n_waves);
+    const uint32_t chunk_rays = trace_chunk(n_active, n_waves);
 #ifdef VR_DIAG
     unsigned long long d_acc[20] = { 0 };
     unsigned long long d_refills = 0;
@@ -386,6 +538,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
         const uint64_t tap_base = (uint64_t)k * frame_pixels;
 
         VrLane L;
+        WaveChunk chunk;
         uint32_t pix = 0;
         bool alive = false, exhausted = false, popping = false;
         unsigned long long a_checked = 0;
@@ -397,18 +550,17 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
             const unsigned long long idle = __ballot(!alive);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (!exhausted && n_idle >= kRefillMin) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&heads[k], n_idle);
-                base = __builtin_amdgcn_readfirstlane(base);
-                const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (!alive && mine < n_active) {
+                uint32_t mine;
+                const bool got = chunk.take(n_idle, (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), &heads[k], n_active, chunk_rays,
+                                            lane, mine);
+                if (!alive && got) {
                     const float4 r = ray_dt[mine];
                     pix = ray_pix[mine];
                     vr_lane_begin(L, stack, v, r.x, r.y, r.z, r.w);
                     alive = true;
                     popping = false;
                 }
-                exhausted = base + n_idle >= n_active;
+                exhausted = chunk.exhausted();
 #ifdef VR_DIAG
                 d_refills++;
 #endif
@@ -506,21 +658,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
 #endif
         }
 
-        /* ---- per-iso counters: one atomic per wave and counter ---- */
-        if (stats) {
-            const unsigned long long c_checked = wave_sum64(a_checked);
-            const uint32_t c_hit = wave_sum(a_hit), c_miss = wave_sum(a_miss), c_moves = wave_sum(a_moves);
-            const uint32_t c_esc = wave_sum(a_esc), c_err = wave_sum(a_err);
-            if (lane == 0) {
-                vr_render_stats *s = stats + k;
-                add_stat(&s->nodes_checked, c_checked);
-                add_stat(&s->hit_count, c_hit);
-                add_stat(&s->miss_count, c_miss);
-                add_stat(&s->escape_help_events, c_esc);
-                add_stat(&s->moves, c_moves);
-                add_stat(&s->errors, c_err);
-            }
-        }
+        /* ---- per-iso counters ---- */
+        if (stats) wave_stats_out(stats, slots, k, gw, n_waves, lane, a_checked, a_hit, a_miss, a_esc, a_moves, a_err);
     }
 #ifdef VR_DIAG
     {
@@ -624,6 +763,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     uint32_t d_lane_traces = 0, d_lane_emit = 0;
 #endif
     VrLane L;
+    WaveChunk chunk;
     VrIsoUpper track;
     track.upper = 255u;
     uint32_t pix = 0, iso = 0, iso_last = 0, cell0 = 0, moves = 0, esc = 0;
@@ -635,11 +775,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
         const unsigned long long idle = __ballot(!alive);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (!exhausted && n_idle >= kSweepRefillMin) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(head, n_idle);
-            base = __builtin_amdgcn_readfirstlane(base);
-            const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!alive && mine < n_items) {
+            uint32_t mine;
+            const bool got = chunk.take(n_idle, (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), head, n_items, VR_SWEEP_CHUNK ? VR_SWEEP_CHUNK : n_idle, lane, mine);
+            if (!alive && got) {
                 const uint32_t grp = mine / (64u * n_blocks), in = mine - grp * 64u * n_blocks;
                 const uint32_t blk = in >> 6, ray = grp * 64u + (in & 63u);
                 const float4 r = ray_dt[ray < n_active ? ray : 0u];
@@ -654,7 +792,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 alive = ray < n_active; /* the last group of 64 may be short */
                 popping = false;
             }
-            exhausted = (uint64_t)base + n_idle >= n_items;
+            exhausted = chunk.exhausted();
 #ifdef VR_DIAG
             if (exhausted && !d_exh) { d_exh = __builtin_amdgcn_s_memtime(); d_rexh = __builtin_amdgcn_s_memrealtime(); }
 #endif
@@ -903,7 +1041,8 @@ template <bool TAPS>
 __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
     VrViewK v, const uint32_t *__restrict__ nodes, const float4 *__restrict__ ray_dt, const uint32_t *__restrict__ ray_pix,
     const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ heads, uint32_t iso_begin, uint32_t iso_count,
-    uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats, VrTapsK taps)
+    uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats, WaveStats *__restrict__ slots,
+    VrTapsK taps)
 {
     extern __shared__ uint32_t s_dyn[];
     LdsPath<kWideThreads> path{ s_dyn + threadIdx.x };
@@ -914,6 +1053,7 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
     const uint32_t waves_per_block = kWideThreads / 64u;
     const uint32_t n_waves = gridDim.x * waves_per_block, gw = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const uint32_t k0 = (uint32_t)(((uint64_t)gw * iso_count) / n_waves);
+    const uint32_t chunk_rays = trace_chunk(n_active, n_waves);
 #ifdef VR_DIAG
     unsigned long long d_acc[20] = { 0 };
     DIAG_T(d_begin);
@@ -927,6 +1067,7 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
         const uint64_t tap_base = (uint64_t)k * frame_pixels;
 
         VrWideLane L;
+        WaveChunk chunk;
         uint32_t pix = 0;
         bool alive = false, exhausted = false, popping = false;
         unsigned long long a_checked = 0;
@@ -937,18 +1078,17 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
             const unsigned long long idle = __ballot(!alive);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (!exhausted && n_idle >= kRefillMin) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&heads[k], n_idle);
-                base = __builtin_amdgcn_readfirstlane(base);
-                const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (!alive && mine < n_active) {
+                uint32_t mine;
+                const bool got = chunk.take(n_idle, (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), &heads[k], n_active, chunk_rays,
+                                            lane, mine);
+                if (!alive && got) {
                     const float4 r = ray_dt[mine];
                     pix = ray_pix[mine];
                     vr_wide_begin(L, v, r.x, r.y, r.z, r.w);
                     alive = true;
                     popping = false;
                 }
-                exhausted = base + n_idle >= n_active;
+                exhausted = chunk.exhausted();
             }
             if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
             DIAG_T(d_t1);
@@ -1015,20 +1155,7 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
 #endif
         }
 
-        if (stats) {
-            const unsigned long long c_checked = wave_sum64(a_checked);
-            const uint32_t c_hit = wave_sum(a_hit), c_miss = wave_sum(a_miss), c_moves = wave_sum(a_moves);
-            const uint32_t c_esc = wave_sum(a_esc), c_err = wave_sum(a_err);
-            if (lane == 0) {
-                vr_render_stats *s = stats + k;
-                add_stat(&s->nodes_checked, c_checked);
-                add_stat(&s->hit_count, c_hit);
-                add_stat(&s->miss_count, c_miss);
-                add_stat(&s->escape_help_events, c_esc);
-                add_stat(&s->moves, c_moves);
-                add_stat(&s->errors, c_err);
-            }
-        }
+        if (stats) wave_stats_out(stats, slots, k, gw, n_waves, lane, a_checked, a_hit, a_miss, a_esc, a_moves, a_err);
     }
 #ifdef VR_DIAG
     {
@@ -1045,6 +1172,7 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
 struct Prepass {
     float4 *ray_dt;
     uint32_t *ray_pix, *n_active, *heads;
+    WaveStats *slots; /* kSlotIsoMax x kSlotWaveMax records */
 };
 
 hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_count, uint32_t row_begin, uint32_t n_rows,
@@ -1052,30 +1180,28 @@ hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_
                           uint32_t oob_word, void *workspace, Prepass &pp)
 {
     const size_t n_pix = (size_t)view.width * n_rows;
-    const uint32_t n_tiles = padded_tiles(view.width, n_rows);
+    const uint32_t n_blocks = padded_tiles(view.width, n_rows) / (kSuper * kSuper);
     char *w = (char *)workspace;
     pp.ray_dt = (float4 *)w;
     w += (n_pix * sizeof(float4) + 255) & ~(size_t)255;
     pp.ray_pix = (uint32_t *)w;
     w += (n_pix * sizeof(uint32_t) + 255) & ~(size_t)255;
-    uint32_t *tile_cnt = (uint32_t *)w;
-    w += ((size_t)n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255;
+    uint32_t *block_cnt = (uint32_t *)w;
+    w += ((size_t)n_blocks * sizeof(uint32_t) + 255) & ~(size_t)255;
     pp.n_active = (uint32_t *)w;
     w += 256;
+    pp.slots = (WaveStats *)w;
+    w += sizeof(WaveStats) * kSlotIsoMax * kSlotWaveMax;
     pp.heads = (uint32_t *)w;
 
     hipError_t e;
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
-    if ((e = hipMemsetAsync(pp.heads, 0, (size_t)iso_count * sizeof(uint32_t), stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
-    const uint32_t tile_blocks = (n_tiles + 3u) / 4u;
-    hipLaunchKernelGGL(vr_k_count, dim3(tile_blocks), dim3(256), 0, stream, view, row_begin, n_rows, n_tiles, center_out, tile_cnt);
-    hipLaunchKernelGGL(vr_k_scan, dim3(1), dim3(1024), 0, stream, tile_cnt, n_tiles, pp.n_active);
-    hipLaunchKernelGGL(vr_k_compact, dim3(tile_blocks), dim3(256), 0, stream, view, row_begin, n_rows, n_tiles, center_out, tile_cnt,
+    hipLaunchKernelGGL(vr_k_count, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt);
+    hipLaunchKernelGGL(vr_k_scan, dim3(1), dim3(1024), 0, stream, block_cnt, n_blocks, pp.n_active, pp.heads, iso_count, d_stats,
+                       (uint64_t)n_pix);
+    hipLaunchKernelGGL(vr_k_compact, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt,
                        pp.ray_dt, pp.ray_pix);
-    if (d_stats)
-        hipLaunchKernelGGL(vr_k_oob_stats, dim3((iso_count + 255u) / 256u), dim3(256), 0, stream, d_stats, iso_count,
-                           (uint64_t)n_pix, pp.n_active);
     if (any_tap)
         hipLaunchKernelGGL(vr_k_tap_defaults, dim3(2048), dim3(256), 0, stream, taps, (uint64_t)n_pix * iso_count, oob_word);
     return hipGetLastError();
@@ -1128,14 +1254,29 @@ void *vr_noalloc_scratch(int device)
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count)
 {
     const size_t n_pix = (size_t)width * n_rows;
-    const size_t n_tiles = padded_tiles(width, n_rows);
+    const size_t n_blocks = padded_tiles(width, n_rows) / (kSuper * kSuper);
     size_t bytes = 0;
     bytes += (n_pix * sizeof(float4) + 255) & ~(size_t)255; /* ray_dt     */
     bytes += (n_pix * sizeof(uint32_t) + 255) & ~(size_t)255; /* ray_pix    */
-    bytes += (n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255; /* tile count / offset */
+    bytes += (n_blocks * sizeof(uint32_t) + 255) & ~(size_t)255; /* super-tile count / offset */
     bytes += 256;                                               /* n_active   */
+    bytes += sizeof(WaveStats) * kSlotIsoMax * kSlotWaveMax;    /* per-wave counters of short iso ranges */
     bytes += ((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255; /* queue heads */
     return bytes;
+}
+
+/* levels of the tree a persistent block keeps in LDS: what is left of the CU's 160 KiB beside the path stacks (and
+ * the sweep kernel's counters), at most 14 */
+static uint32_t lds_top_levels(uint32_t max_depth, uint64_t n_slots, size_t stat_bytes)
+{
+    const uint32_t stack_levels = max_depth > 0 ? max_depth : 1u;
+    const size_t lds_limit = 160u * 1024u / kTraceBlocksPerCu;
+    const size_t trace_stack_bytes = ((size_t)stack_levels + 1u) * kTraceThreads * sizeof(uint32_t);
+    uint32_t top_levels = 14;
+    while (top_levels > 0 && ((((size_t)1 << top_levels) * sizeof(uint32_t)) + trace_stack_bytes + stat_bytes > lds_limit ||
+                              ((uint64_t)1 << top_levels) > n_slots + 1u))
+        top_levels--;
+    return top_levels;
 }
 
 hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_raw,
@@ -1159,6 +1300,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
         const uint32_t tiles_x = (view.width + kBlockW - 1) / kBlockW;
         const uint32_t tiles_y = (n_rows + kBlockH - 1) / kBlockH;
         dim3 grid(tiles_x * tiles_y, iso_count, 1), block(256, 1, 1);
+        if (d_stats && (e = hipMemsetAsync(d_stats, 0, sizeof(vr_render_stats) * iso_count, stream)) != hipSuccess) return e;
         if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
         switch (variant) {
         case VR_KERNEL_RESTART_GLOBAL:
@@ -1195,30 +1337,35 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     /* persistent grid: kTraceBlocksPerCu blocks per CU.  A block's LDS holds the path stacks and, in what is
      * left of its share of the CU's 160 KiB, the top K levels of the tree (two thirds of all node reads).
      * More than one iso value: the sweep kernel, which shares traversals between iso values. */
-    const size_t lds_limit = 160u * 1024u / kTraceBlocksPerCu;
     const size_t trace_stack_bytes = ((size_t)stack_levels + 1u) * kTraceThreads * sizeof(uint32_t);
     const size_t stat_bytes = sweep ? (size_t)sweep_stat_words(iso_count) * sizeof(uint32_t) : 0u;
-    uint32_t top_levels = 14;
-    if (top_levels > 14) top_levels = 14;
-    while (top_levels > 0 && ((((size_t)1 << top_levels) * sizeof(uint32_t)) + trace_stack_bytes + stat_bytes > lds_limit ||
-                              ((uint64_t)1 << top_levels) > view.n_slots + 1u))
-        top_levels--;
+    const uint32_t top_levels = lds_top_levels(max_depth, view.n_slots, stat_bytes);
     const uint32_t n_top = 1u << top_levels; /* heap positions 0 .. 2^K - 1 = levels 0 .. K-1 (K = 0: the unused slot 0 only) */
     const size_t trace_lds = (size_t)n_top * sizeof(uint32_t) + trace_stack_bytes + stat_bytes;
-    if (trace_lds > lds_limit) return hipErrorInvalidValue;
-    const void *fn = sweep ? (any_tap ? (const void *)vr_k_sweep<true> : (const void *)vr_k_sweep<false>)
-                           : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
+    if (trace_lds > 160u * 1024u / kTraceBlocksPerCu) return hipErrorInvalidValue;
     const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
     const uint64_t frame_pixels = n_pix;
     const uint32_t stack_rows = stack_levels + 1u;
-    void *args[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
-                     (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
-                     (void *)&d_rgb, (void *)&d_stats, (void *)&taps };
+    /* counters of a short iso range: per-wave slots, summed by a small kernel behind the traversal */
+    WaveStats *slots = !sweep && d_stats && iso_count <= kSlotIsoMax && blocks * (kTraceThreads / 64u) <= kSlotWaveMax ? pp.slots : nullptr;
+    void *args_sweep[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
+                           (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
+                           (void *)&d_rgb, (void *)&d_stats, (void *)&taps };
+    void *args_trace[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
+                           (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
+                           (void *)&d_rgb, (void *)&d_stats, (void *)&slots, (void *)&taps };
+    void **args = sweep ? args_sweep : args_trace;
+    const void *fn = sweep ? (any_tap ? (const void *)vr_k_sweep<true> : (const void *)vr_k_sweep<false>)
+                           : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
 
     if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
     if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, trace_lds, stream)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+    if (slots) {
+        hipLaunchKernelGGL(vr_k_sum_slots, dim3(iso_count), dim3(1024), 0, stream, slots, blocks * (kTraceThreads / 64u), d_stats);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
 #ifdef VR_DIAG
     {
         unsigned long long h[20], z[20] = { 0 };
@@ -1278,6 +1425,7 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
     hipError_t e = hipSuccess;
     if (variant == VR_KERNEL_RESTART_GLOBAL || variant == VR_KERNEL_RESTART_LDS || variant == VR_KERNEL_RESUME) {
         const uint32_t tiles = ((view.width + kBlockW - 1) / kBlockW) * ((n_rows + kBlockH - 1) / kBlockH);
+        if (d_stats && (e = hipMemsetAsync(d_stats, 0, sizeof(vr_render_stats) * iso_count, stream)) != hipSuccess) return e;
         if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
         hipLaunchKernelGGL(vr_k_render_wide, dim3(tiles, iso_count), dim3(256), 0, stream, view, d_nodes, iso_begin, row_begin,
                            n_rows, d_rgb, d_stats, taps);
@@ -1294,13 +1442,18 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
     const size_t lds = (size_t)VR_WIDE_MAX_DEPTH * kWideThreads * sizeof(uint32_t);
     const uint32_t blocks = (uint32_t)n_cus * kWideBlocksPerCu;
     const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
+    WaveStats *slots = d_stats && iso_count <= kSlotIsoMax && blocks * (kWideThreads / 64u) <= kSlotWaveMax ? pp.slots : nullptr;
     void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&pp.ray_dt, (void *)&pp.ray_pix, (void *)&pp.n_active,
                      (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels, (void *)&d_rgb,
-                     (void *)&d_stats, (void *)&taps };
+                     (void *)&d_stats, (void *)&slots, (void *)&taps };
     if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
     if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kWideThreads), args, lds, stream)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (ev_end) e = hipEventRecord(ev_end, stream);
+    if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+    if (slots) {
+        hipLaunchKernelGGL(vr_k_sum_slots, dim3(iso_count), dim3(1024), 0, stream, slots, blocks * (kWideThreads / 64u), d_stats);
+        e = hipGetLastError();
+    }
 #ifdef VR_DIAG
     {
         unsigned long long h[20], z[20] = { 0 };
