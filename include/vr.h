@@ -243,6 +243,17 @@ int vr_render_device(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint3
                      uint32_t row_begin, uint32_t row_end, void *d_rgb24, void *d_stats,
                      const vr_taps *d_taps, void *stream);
 
+/* vr_render_device on rows spread over the image in bands, for sharding one frame (or one sweep) over GPUs with an
+ * even load: the rows that never meet the volume sit at the top and the bottom of the image (src/raytrace.zig:40 walks
+ * them in order), so contiguous blocks of rows give the outer ranks nothing to do.  Band j (j < n_bands) = image rows
+ * [row_begin + j * band_pitch, + band_rows); the last band is clipped at the bottom edge of the image.  The bands
+ * are packed one after the other in the output: with n_rows their total number of rows, frame k, packed row r starts
+ * at d_rgb24 + ((k * n_rows + r) * width) * 3, and the taps likewise.  Rank i of n takes row_begin = i * band_rows,
+ * band_pitch = n * band_rows.  No counterpart in the reference (one thread renders all rows). */
+int vr_render_device_bands(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
+                           uint32_t band_rows, uint32_t band_pitch, uint32_t n_bands, void *d_rgb24, void *d_stats,
+                           const vr_taps *d_taps, void *stream);
+
 /* vr_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  No counterpart in the reference (its renderImage allocates nothing
  * either, src/raytrace.zig:11-106, but runs on the CPU).  Same arguments, same results as vr_render_device, but

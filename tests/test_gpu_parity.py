@@ -624,3 +624,110 @@ def test_gpu_span_heuristic_trees_match_host_builder_and_oracle(oracle, c60_vox,
             ref = oracle.render(k.nodes, k.root_dim, pos, forw, up, 96, 96, 2.0, 100)
             assert_same_render(_gpu(r, pos, forw, up, 96, 96, 2.0, 100), ref, "GPU-built %s tree" % h)
     assert built >= 25
+
+
+def test_band_entry_point_equals_whole_frames(oracle, skull_vox, skull_renderer):
+    """vr_render_device_bands: the rows of a sweep dealt out in bands to 3 ranks (uneven: 200 rows = 7 bands of 32,
+    the last one short), every rank's packed output put back in place, equals the sweep rendered whole -- frames,
+    taps and the sum of the per-iso counters; also bands that are not a multiple of the tile height."""
+    import torch
+    from volumerenderer_amd import sharding
+    pos, forw, up = oracle.main_camera(skull_vox.shape)
+    L = capi.lib()
+    for W, H, band, world, b, n in [(256, 200, 32, 3, 70, 12), (96, 61, 5, 4, 80, 1), (64, 64, 32, 8, 0, 9)]:
+        v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+        whole = skull_renderer.renderSweep(pos, forw, up, W, H, 2.0, b, n, taps=True)
+        rgb = np.zeros((n, H, W, 3), np.uint8)
+        checked = np.zeros((n, H, W), np.uint32)
+        stats = np.zeros((n, 7), np.int64)
+        for rank in range(world):
+            sh = sharding.band_shard(rank, world, H, band)
+            if sh["n_bands"] == 0:
+                continue
+            rows = sharding.band_rows_of(rank, world, H, band)
+            d_rgb = torch.full((n, sh["n_rows"], W, 3), 3, dtype=torch.uint8, device="cuda")
+            d_chk = torch.zeros((n, sh["n_rows"], W), dtype=torch.int32, device="cuda")
+            d_stats = torch.zeros((n, 7), dtype=torch.int64, device="cuda")
+            taps = capi.Taps(None, None, d_chk.data_ptr(), None)
+            capi.check(L.vr_render_device_bands(skull_renderer.handle, C.byref(v), b, n, sh["row_begin"], sh["band_rows"],
+                                                sh["band_pitch"], sh["n_bands"], d_rgb.data_ptr(), d_stats.data_ptr(),
+                                                C.byref(taps), None), "vr_render_device_bands")
+            capi.check(L.vr_sync(skull_renderer.handle), "vr_sync")
+            rgb[:, rows] = d_rgb.cpu().numpy()
+            checked[:, rows] = d_chk.cpu().numpy().view(np.uint32)
+            stats += d_stats.cpu().numpy()
+        assert (rgb == whole["rgb"]).all() and (checked == whole["checked"]).all(), (W, H, band, world)
+        for k in range(n):
+            ws = whole["stats"][k]
+            assert list(stats[k]) == [ws[f] for f in ("nodes_checked", "hit_count", "miss_count", "oob_count",
+                                                       "escape_help_events", "moves", "errors")]
+    v = vr.raytrace._view(pos, forw, up, 64, 64, 2.0)
+    d = torch.zeros(64 * 64 * 3, dtype=torch.uint8, device="cuda")
+    assert L.vr_render_device_bands(skull_renderer.handle, C.byref(v), 0, 1, 40, 32, 16, 2, d.data_ptr(), None, None, None) == capi.VR_EARG
+    assert L.vr_render_device_bands(skull_renderer.handle, C.byref(v), 0, 1, 0, 32, 32, 3, d.data_ptr(), None, None, None) == capi.VR_EARG
+
+
+def _two_rank_worker(rank, world, port, tmp):
+    """One of two gloo ranks that share GPU 0: renders its band shard and its iso shard of a Skull sweep with the
+    product (vr_render_device_bands / vr_render_device on a stream of its own), gathers to rank 0."""
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from volumerenderer_amd import sharding
+    data = vr.Data.loadUCD(os.path.join(root, "tests", "data", "Skull.vol.gz"))
+    pos, forw, up = vr.main_camera(data.resulution)
+    W, H, b, n = 320, 200, 72, 16
+    L = capi.lib()
+    v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream()
+    with vr.Renderer(0) as r, torch.cuda.stream(stream):
+        r.upload_volume(data)
+        r.build_kdt("AlwaysCenter")
+        # rows in bands, all iso values on every rank
+        sh = sharding.band_shard(rank, world, H)
+        d_rgb = torch.empty((n, sh["n_rows"], W, 3), dtype=torch.uint8, device="cuda")
+        d_stats = torch.zeros((n, 7), dtype=torch.int64, device="cuda")
+        capi.check(L.vr_render_device_bands(r.handle, C.byref(v), b, n, sh["row_begin"], sh["band_rows"], sh["band_pitch"],
+                                            sh["n_bands"], d_rgb.data_ptr(), d_stats.data_ptr(), None,
+                                            C.c_void_p(stream.cuda_stream)), "vr_render_device_bands")
+        rows = [sharding.band_rows_of(k, world, H) for k in range(world)]
+        banded = sharding.gather_rows(d_rgb.cpu(), rows, H, dst=0)  # .cpu() waits on the stream the render is on
+        st_rows = d_stats.cpu()
+        dist.reduce(st_rows, dst=0)
+        # iso values in blocks, whole frames on every rank
+        ib, ic = sharding.iso_shard(rank, world, b, n)
+        d_rgb2 = torch.empty((ic, H, W, 3), dtype=torch.uint8, device="cuda")
+        d_stats2 = torch.zeros((ic, 7), dtype=torch.int64, device="cuda")
+        capi.check(L.vr_render_device(r.handle, C.byref(v), ib, ic, 0, H, d_rgb2.data_ptr(), d_stats2.data_ptr(), None,
+                                      C.c_void_p(stream.cuda_stream)), "vr_render_device")
+        counts = [sharding.iso_shard(k, world, b, n)[1] for k in range(world)]
+        by_iso = sharding.gather_frames(d_rgb2.cpu(), counts, dst=0)
+        st_iso = sharding.gather_frames(d_stats2.cpu(), counts, dst=0)
+        if rank == 0:
+            whole = r.renderSweep(pos, forw, up, W, H, 2.0, b, n)
+            ref_stats = np.array([[s[f] for f in ("nodes_checked", "hit_count", "miss_count", "oob_count",
+                                                  "escape_help_events", "moves", "errors")] for s in whole["stats"]])
+            assert (banded.numpy() == whole["rgb"]).all() and (by_iso.numpy() == whole["rgb"]).all()
+            assert (st_rows.numpy() == ref_stats).all() and (st_iso.numpy() == ref_stats).all()
+            assert whole["rgb"].any()
+            open(os.path.join(tmp, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_render_their_shards_with_the_product(tmp_path):
+    """The product under a process group: two ranks (sharing GPU 0 here, one GPU each on a node) render band shards
+    and iso shards of a sweep through the C ABI and gather them; rank 0 compares with the sweep rendered whole."""
+    import os
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.get_context("spawn")
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()

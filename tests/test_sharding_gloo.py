@@ -25,6 +25,22 @@ def test_split_range_covers_everything():
     assert sharding.row_shard(1, 2, 4096) == (2048, 4096)
 
 
+def test_band_shards_cover_every_row_once():
+    for height in (1, 31, 32, 33, 100, 1024, 1030):
+        for world in (1, 2, 3, 8):
+            for band in (8, 32):
+                rows = []
+                for r in range(world):
+                    sh = sharding.band_shard(r, world, height, band)
+                    mine = sharding.band_rows_of(r, world, height, band)
+                    assert len(mine) == sh["n_rows"] and sh["band_pitch"] == world * band
+                    if sh["n_bands"]:
+                        assert mine[0] == sh["row_begin"] and sh["row_begin"] + (sh["n_bands"] - 1) * sh["band_pitch"] < height
+                    rows += mine
+                assert sorted(rows) == list(range(height)), (height, world, band)
+    assert sharding.band_shard(3, 8, 1024) == {"row_begin": 96, "band_rows": 32, "band_pitch": 256, "n_bands": 4, "n_rows": 128}
+
+
 def _worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -51,7 +67,18 @@ def _worker(rank, world, port, tmp):
     frame = sharding.gather_frames(torch.from_numpy(img[r0:r1].copy()), [b - a for a, b in rows], dst=0)
     nc = torch.tensor([st.nodes_checked], dtype=torch.int64)
     dist.reduce(nc, dst=0)
+    # band sharding of a 2-frame sweep: bands of 8 rows dealt out round-robin (49 rows: 4 + 3 bands, the last one short)
+    mine = sharding.band_rows_of(rank, world, H2, 8)
+    part = np.zeros((2, len(mine), W, 3), np.uint8)
+    for k, iso in enumerate((100, 101)):
+        whole = np.zeros((H2, W, 3), np.uint8)
+        for first in range(rank * 8, H2, world * 8):
+            O.render(nodes, rd, pos, forw, up, W, H2, 2.0, iso, rows=(first, min(first + 8, H2)), taps=False, out=whole)
+        part[k] = whole[mine]
+    banded = sharding.gather_rows(torch.from_numpy(part), [sharding.band_rows_of(r, world, H2, 8) for r in range(world)], H2, dst=0)
     if rank == 0:
+        for k, iso in enumerate((100, 101)):
+            assert (banded[k].numpy() == O.render(nodes, rd, pos, forw, up, W, H2, 2.0, iso, taps=False)["rgb"]).all()
         ref = np.stack([O.render(nodes, rd, pos, forw, up, W, H, 2.0, i, taps=False)["rgb"] for i in range(100, 105)])
         assert (full.numpy() == ref).all()
         assert int(checked) == 5
@@ -60,7 +87,7 @@ def _worker(rank, world, port, tmp):
         assert int(nc) == ref2["stats"].nodes_checked
         open(os.path.join(tmp, "ok"), "w").write("ok")
     else:
-        assert full is None and frame is None
+        assert full is None and frame is None and banded is None
     dist.barrier()
     dist.destroy_process_group()
 

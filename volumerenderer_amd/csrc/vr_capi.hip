@@ -377,8 +377,9 @@ int vr_download_kdt_wide(vr_ctx *c, uint32_t *nodes_out, uint64_t first_slot, ui
  * (fixed_bytes long) and nothing is allocated or created. */
 static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
                          uint32_t row_end, void *d_rgb24, void *d_stats, const vr_taps *d_taps, void *stream,
-                         void *fixed_scratch, size_t fixed_bytes)
+                         void *fixed_scratch, size_t fixed_bytes, uint32_t band_rows = 0, uint32_t band_pitch = 0)
 {
+    /* [row_begin, row_end) counts OUTPUT rows from image row row_begin on; with bands they are spread over the image */
     if (!c || !d_rgb24) return VR_EARG;
     int rc = check_view(view);
     if (rc != VR_OK) return rc;
@@ -388,6 +389,8 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
     VR_HIP(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     VrViewK k = make_view(c, view);
+    k.band_rows = band_rows;
+    k.band_pitch = band_pitch;
     VrTapsK taps = { nullptr, nullptr, nullptr, nullptr };
     if (d_taps) {
         taps.cell_flag = d_taps->cell_flag;
@@ -437,6 +440,20 @@ int vr_render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_
                      uint32_t row_end, void *d_rgb24, void *d_stats, const vr_taps *d_taps, void *stream)
 {
     return render_device(c, view, iso_begin, iso_count, row_begin, row_end, d_rgb24, d_stats, d_taps, stream, nullptr, 0);
+}
+
+int vr_render_device_bands(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
+                           uint32_t band_rows, uint32_t band_pitch, uint32_t n_bands, void *d_rgb24, void *d_stats,
+                           const vr_taps *d_taps, void *stream)
+{
+    if (!view || band_rows == 0 || n_bands == 0 || band_pitch < band_rows) return VR_EARG;
+    const uint64_t last = (uint64_t)row_begin + (uint64_t)(n_bands - 1u) * band_pitch; /* first row of the last band */
+    if (last >= view->height) return VR_EARG;
+    const uint32_t last_rows = view->height - (uint32_t)last < band_rows ? view->height - (uint32_t)last : band_rows;
+    const uint64_t n_rows = (uint64_t)(n_bands - 1u) * band_rows + last_rows;
+    if (row_begin + n_rows > view->height) return VR_EARG; /* cannot happen with pitch >= rows; keeps the shared checks valid */
+    return render_device(c, view, iso_begin, iso_count, row_begin, row_begin + (uint32_t)n_rows, d_rgb24, d_stats, d_taps, stream,
+                         nullptr, 0, n_bands > 1u ? band_rows : 0u, band_pitch);
 }
 
 int vr_render_device_noalloc(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,

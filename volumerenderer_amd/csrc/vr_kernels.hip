@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void vr_k_render(VrViewK v, const uint32_t *__
     VrHit h;
     h.t = 0.0f; h.flag = VR_FLAG_OOB; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
     if (valid) {
-        VrRay ray = vr_make_ray(v, xi, yr + row_begin);
+        VrRay ray = vr_make_ray(v, xi, row_begin + vr_band_row(v, yr));
         if (VARIANT == VR_KERNEL_RESTART_GLOBAL) {
             h = vr_trace_restart(v, ray, iso, GlobalFetch{ nodes });
         } else if (VARIANT == VR_KERNEL_RESTART_LDS) {
@@ -235,7 +235,7 @@ __device__ __forceinline__ bool tile_ray(const VrViewK &v, uint32_t tile, uint32
     const uint32_t yr = (row * kSuper + in / kSuper) * kTileH + (lane >> 3);
     pix = yr * v.width + xi;
     if (xi >= v.width || yr >= n_rows) return false;
-    ray = vr_make_ray(v, xi, yr + row_begin);
+    ray = vr_make_ray(v, xi, row_begin + vr_band_row(v, yr));
     return !ray.oob;
 }
 
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(256) void vr_k_render_wide(VrViewK v, const uint32_
     VrHit h;
     h.t = 0.0f; h.flag = VR_FLAG_OOB; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
     if (valid) {
-        const VrRay ray = vr_make_ray(v, xi, yr + row_begin);
+        const VrRay ray = vr_make_ray(v, xi, row_begin + vr_band_row(v, yr));
         LdsPath<256u> path{ s_path + threadIdx.x };
         h = vr_trace_wide(v, ray, iso, WideFetch{ nodes }, path);
         const uint64_t pix = ((uint64_t)blockIdx.y * n_rows + yr) * v.width + xi;

@@ -88,7 +88,18 @@ struct VrViewK {
     uint32_t root_hi;   /* packed root_dim (src/SlimKDT.zig:55-64: root box = [0, root_dim)) */
     uint32_t rdx, rdy, rdz;
     uint64_t n_slots;
+    /* a call may render the rows of the image in bands: output row p (counted from the first row of the call)
+     * is image row  first + (p / band_rows) * band_pitch + p % band_rows;  band_rows = 0: one contiguous block */
+    uint32_t band_rows = 0, band_pitch = 0;
 };
+
+/* image row, relative to the first row of the call, of output row p */
+VR_HD uint32_t vr_band_row(const VrViewK &v, uint32_t p)
+{
+    if (v.band_rows == 0u) return p;
+    const uint32_t band = p / v.band_rows;
+    return band * v.band_pitch + (p - band * v.band_rows);
+}
 
 struct VrRay {
     float dx, dy, dz;
