@@ -6,35 +6,40 @@ One step = one pass of the hot path over one batch of work: the reference driver
 reference camera (src/main.zig:31-43), i.e. 256 x 1 048 576 primary rays per step.  All primary
 rays count, including the ones that miss the volume -- the reference's ms/frame includes them too.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--gather] [--in-flight F]
-                    [--shard iso|rows] [--kernel V] [--width PX] [--volume skull|c60|standin256|gyroid1024]
-                    [--iso-begin B] [--iso-count N] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling auto|weak|strong] [--shard bands|rows|iso]
+                    [--gather] [--no-extras] [--in-flight F] [--kernel V] [--width PX]
+                    [--volume skull|c60|standin256|gyroid1024] [--iso-begin B] [--iso-count N] [--no-cpu-baseline]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`
 (one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE from the environment).  The path shards with no
 data-path collective: every rank holds a replica of the node array.
-  weak   (default) each rank renders the whole 256-iso sweep; the job is N sweeps
-  strong the 256 iso values of ONE sweep are split into N contiguous blocks (north-star sharding), or,
-         with --shard rows, the rows of every frame
---gather adds the one real exchange step: framebuffers are gathered to rank 0 over RCCL inside the
-timed region.
+  strong (what `auto` picks for N > 1) ONE sweep is split over the ranks: the rows of every frame in bands of 32
+         dealt out round-robin (--shard bands, the split that keeps every rank's load equal and the sharing of
+         traversals between iso values intact), contiguous blocks of rows (rows), or blocks of iso values (iso)
+  weak   each rank renders a whole sweep; the job is N sweeps
+For N > 1 the line carries the main figure (`value`, the scaling named in `scaling`) and, unless --no-extras,
+the other ones measured in the same run: `weak_scaling`, and `strong_with_gather` (the split sweep with the
+framebuffers gathered to rank 0 over RCCL inside the timed region -- the one real exchange step).
 
-Inputs (node array) and outputs (RGB24 frames) are resident in HBM across the timed region; the
-PCIe copy of the frames to the host is not part of `value`.
+Inputs (node array) and outputs (RGB24 frames) are resident in HBM across the timed region; `value_host_delivered`
+(N = 1) is the same sweep delivered into page-locked host memory by vr_render_sweep, which is what the
+reference's timed call (src/main.zig:119-135) hands its caller -- never part of `value`.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the traversal kernel against the HBM peak with the
 ALGORITHMIC bytes 4 * nodes_checked + 3 * pixels (one 4-byte SlimNode per reference loop iteration,
 src/raytrace.zig:162,177, plus one RGB24 store per pixel, :54-67), its duration measured with HIP
-events on the launch stream.  `cpu_baseline` times the CPU oracle (a port of the reference's
-single-threaded path; the Zig reference cannot be built offline) on one host core on a bounded
-sample of the same workload; `cpu_all_cores` is the same oracle with the image rows spread over the
-host cores this job may use -- a whole-socket figure the reference itself does not have.
-`roofline.measured_copy_GBps` is a device-to-device copy timed in the same process (the HBM ceiling
-actually reachable, next to the nominal peak); `roofline.counters` repeats the VALU figures of the
-committed rocprofv3 counter pass.
+events on the launch stream.  Next to that contract figure it reports what the kernel really does: the sweep
+kernel's own count of traversals and the share of its run time after its queue ran empty (live, from the kernel),
+and HBM traffic / VALU lane utilisation from the committed rocprofv3 counter pass of the same workload
+(profiles/r02_pmc_<workload>.json), flagged `counters_stale` when the kernel sources have changed since.
+`cpu_baseline` times the CPU oracle (a port of the reference's single-threaded path; the Zig reference cannot be
+built offline) on one host core on a bounded sample of the same workload; `cpu_all_cores` is the same oracle
+with the image rows spread over the host cores this job may use -- a whole-socket figure the reference itself
+does not have.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -45,6 +50,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+KERNEL_SOURCES = ["vr_kernels.hip", "vr_trace_core.h", "vr_trace_wide.h"]
+
+
+def kernel_sources_sha():
+    """Fingerprint of the kernel sources a counter summary belongs to."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "volumerenderer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(kdt, pos, forw, up, width, iso_begin=0, iso_count=256, budget_s=20.0):
@@ -113,17 +128,33 @@ def copy_ceiling_gbps(torch):
     return 2.0 * (1 << 30) / (best * 1e-3) / 1e9
 
 
-def profile_counters():
-    """VALU figures of the committed counter pass (profiles/r01_pmc_summary.json), for the default workload."""
+def profile_counters(workload, kernel, kernel_ms):
+    """HBM traffic and VALU figures of the committed counter pass of this workload, with the fingerprint of the
+    kernel sources they were taken on; stale = the sources of the tree this runs in differ."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload)
     try:
-        s = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        k = [v for n, v in s.items() if "vr_k_sweep" in n][0]
+        s = json.load(open(path))
+        k = s["kernels"][kernel]
+    except (OSError, ValueError, KeyError):
+        return None, None, None
+    out = {"source": os.path.relpath(path, ROOT), "kernel_sources_sha": s.get("kernel_sources_sha"),
+           "commit": s.get("commit")}
+    stale = s.get("kernel_sources_sha") != kernel_sources_sha()
+    traffic = None
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+        # rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies the 128-byte fabric read requests at 64 bytes
+        # each, so it is doubled; per launch
+        traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    if "SQ_ACTIVE_INST_VALU" in k and "GRBM_GUI_ACTIVE" in k:
         simd_quanta = k["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0  # cycles per XCD / 4-cycle issue slots x 1024 SIMDs
-        return {"valu_busy_frac": k["SQ_ACTIVE_INST_VALU"] / simd_quanta,
-                "valu_lane_util_frac": k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"]),
-                "waves_per_simd": k["SQ_WAVES"] / 1024.0, "source": "profiles/r01_pmc_summary.json"}
-    except (OSError, ValueError, KeyError, IndexError):
-        return None
+        out["valu_busy_frac"] = k["SQ_ACTIVE_INST_VALU"] / simd_quanta
+    if "SQ_THREAD_CYCLES_VALU" in k and "SQ_ACTIVE_INST_VALU" in k:
+        out["valu_lane_util_frac"] = k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"])
+    if "SQ_WAVES" in k:
+        out["waves_per_simd"] = k["SQ_WAVES"] / 1024.0
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in k and "TCP_TCC_READ_REQ_sum" in k and k["TCP_TOTAL_CACHE_ACCESSES_sum"]:
+        out["l1_hit_frac"] = 1.0 - k["TCP_TCC_READ_REQ_sum"] / k["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    return out, traffic, stale
 
 
 def main():
@@ -131,10 +162,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--shard", choices=["iso", "rows"], default="iso",
-                    help="with --scaling strong: split the iso values (default) or the image rows over the ranks")
-    ap.add_argument("--gather", action="store_true")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
+                    help="auto: strong for N > 1 (one sweep split over the ranks), with the weak figure as an extra")
+    ap.add_argument("--shard", choices=["bands", "rows", "iso"], default="bands",
+                    help="strong scaling: rows in bands of 32 dealt out round-robin (default), contiguous row blocks, or iso blocks")
+    ap.add_argument("--gather", action="store_true", help="gather the framebuffers to rank 0 inside the timed region of the main figure")
+    ap.add_argument("--no-extras", action="store_true", help="N > 1: only the main figure, not the other scaling / the gather variant")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--volume", choices=["skull", "c60", "standin256", "gyroid1024"], default="skull")
@@ -147,7 +180,6 @@ def main():
                          "the default 1 runs the steps strictly one after the other")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -175,6 +207,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+    if args.in_flight < 1 or (args.in_flight > 1 and (args.gather or world > 1)):
+        raise SystemExit("--in-flight must be >= 1 and goes with one GPU and no gather")
 
     W = H = args.width
     if args.volume == "skull":
@@ -203,44 +238,61 @@ def main():
     build = r.build_kdt("AlwaysCenter")  # centre-split tree built on the GPU from the uploaded volume
     build_ms = (time.perf_counter() - tb) * 1e3
     r.set_kernel(args.kernel)
-    row_begin, row_end = 0, H
-    if args.scaling == "strong" and args.shard == "rows":
-        if args.gather:
-            raise SystemExit("--gather goes with iso sharding")
-        iso_begin, iso_count = I0, IN
-        counts = [IN] * world
-        row_begin, row_end = sharding.row_shard(rank, world, H)
-    elif args.scaling == "strong":
-        iso_begin, iso_count = sharding.iso_shard(rank, world, I0, IN)
-        counts = [sharding.iso_shard(k, world, I0, IN)[1] for k in range(world)]
-    else:
-        iso_begin, iso_count = I0, IN
-        counts = [IN] * world
     view = vr.raytrace._view(pos, forw, up, W, H, 2.0)
-    d_rgb = torch.empty((iso_count, row_end - row_begin, W, 3), dtype=torch.uint8, device="cuda")
-    d_stats = torch.zeros((iso_count, 7), dtype=torch.int64, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    # --in-flight > 1: further slots, each with its own context (scratch), stream and output buffers
-    if args.in_flight < 1 or (args.in_flight > 1 and args.gather):
-        raise SystemExit("--in-flight must be >= 1 and does not go with --gather")
-    slots = [(r, d_rgb, d_stats, None)]
-    for _ in range(1, args.in_flight):
-        r2 = vr.Renderer(local_rank)
-        r2.upload_volume(data)
-        r2.build_kdt("AlwaysCenter")
-        r2.set_kernel(args.kernel)
-        s2 = torch.cuda.Stream()
-        slots.append((r2, torch.empty_like(d_rgb), torch.zeros_like(d_stats), s2))
-    step_no = [0]
+    # A stream of our own: NULL would mean the context's private non-blocking stream, which torch's streams do not
+    # order against -- the gather (and any copy torch makes) has to come behind the render on one stream.
+    stream = torch.cuda.Stream()
+    sp = C.c_void_p(stream.cuda_stream)
 
-    def step():
-        rr, rgb_k, stats_k, s_k = slots[step_no[0] % len(slots)]
-        step_no[0] += 1
-        capi.check(L.vr_render_device(rr.handle, C.byref(view), iso_begin, iso_count, row_begin, row_end, rgb_k.data_ptr(),
-                                      stats_k.data_ptr(), None, C.c_void_p(s_k.cuda_stream if s_k else stream)),
-                   "vr_render_device")
-        if args.gather and world > 1:
-            sharding.gather_frames(d_rgb.cpu() if rehearsal else d_rgb, counts, dst=0)
+    class Plan:
+        """What this rank renders in one step of one scaling mode, and how the parts go back together."""
+
+        def __init__(self, mode, shard):
+            self.mode, self.shard = mode, shard
+            self.iso_begin, self.iso_count, self.bands = I0, IN, None
+            self.row_begin, self.row_end = 0, H
+            self.row_lists = None
+            if mode == "strong" and world > 1:
+                if shard == "iso":
+                    self.iso_begin, self.iso_count = sharding.iso_shard(rank, world, I0, IN)
+                    self.counts = [sharding.iso_shard(k, world, I0, IN)[1] for k in range(world)]
+                elif shard == "rows":
+                    self.row_begin, self.row_end = sharding.row_shard(rank, world, H)
+                    self.row_lists = [list(range(*sharding.row_shard(k, world, H))) for k in range(world)]
+                else:
+                    self.bands = sharding.band_shard(rank, world, H)
+                    self.row_lists = [sharding.band_rows_of(k, world, H) for k in range(world)]
+            self.n_rows = self.bands["n_rows"] if self.bands else self.row_end - self.row_begin
+            self.rays = self.iso_count * W * self.n_rows
+            self.d_rgb = torch.empty((max(1, self.iso_count), max(1, self.n_rows), W, 3), dtype=torch.uint8, device="cuda")
+            self.d_stats = torch.zeros((max(1, self.iso_count), 7), dtype=torch.int64, device="cuda")
+
+        def render(self, rr, rgb, stats, s):
+            if self.rays == 0:
+                return
+            if self.bands:
+                b = self.bands
+                capi.check(L.vr_render_device_bands(rr.handle, C.byref(view), self.iso_begin, self.iso_count, b["row_begin"],
+                                                    b["band_rows"], b["band_pitch"], b["n_bands"], rgb.data_ptr(),
+                                                    stats.data_ptr(), None, s), "vr_render_device_bands")
+            else:
+                capi.check(L.vr_render_device(rr.handle, C.byref(view), self.iso_begin, self.iso_count, self.row_begin,
+                                              self.row_end, rgb.data_ptr(), stats.data_ptr(), None, s), "vr_render_device")
+
+        def gather(self):
+            local = self.d_rgb.cpu() if rehearsal else self.d_rgb
+            if self.row_lists is not None:
+                return sharding.gather_rows(local, self.row_lists, H, dst=0)
+            if self.mode == "strong" and self.shard == "iso":
+                return sharding.gather_frames(local, self.counts, dst=0)
+            return sharding.gather_frames(local, [IN] * world, dst=0)
+
+        def describe(self):
+            if world == 1:
+                return "none"
+            if self.mode == "weak":
+                return "one sweep per rank"
+            return {"iso": "iso-blocks", "rows": "row-blocks", "bands": "row-bands of 32, round-robin"}[self.shard]
 
     def fence():
         torch.cuda.synchronize()
@@ -248,58 +300,102 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    capi.check(L.vr_set_timing(r.handle, 1), "vr_set_timing")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    capi.check(L.vr_set_timing(r.handle, 0), "vr_set_timing")
-    tot_ms, launches = C.c_double(), C.c_uint32()
-    capi.check(L.vr_timing_read(r.handle, C.byref(tot_ms), C.byref(launches)), "vr_timing_read")
-    if args.in_flight > 1:
-        # kernels of overlapping steps wait for each other's CUs, so their event intervals say nothing about the
-        # kernel: time it in a short pass of its own, one step after the other (outside the timed region)
-        capi.check(L.vr_set_timing(r.handle, 1), "vr_set_timing")
-        for _ in range(3):
-            step_no[0] = 0
+    def measure(plan, gather, slots=None):
+        """W warmup steps, then exactly K timed steps between barriers; returns (max-over-ranks seconds, rays per step
+        of the whole job, kernel ms per launch on this rank)."""
+        slots = slots or [(r, plan.d_rgb, plan.d_stats, stream)]
+        step_no = [0]
+
+        def step():
+            rr, rgb_k, stats_k, s_k = slots[step_no[0] % len(slots)]
+            step_no[0] += 1
+            with torch.cuda.stream(s_k):
+                plan.render(rr, rgb_k, stats_k, C.c_void_p(s_k.cuda_stream))
+                if gather and world > 1:
+                    plan.gather()
+
+        for _ in range(args.warmup):
             step()
-            torch.cuda.synchronize()
+        fence()
+        capi.check(L.vr_set_timing(r.handle, 1), "vr_set_timing")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
         capi.check(L.vr_set_timing(r.handle, 0), "vr_set_timing")
+        tot_ms, launches = C.c_double(), C.c_uint32()
         capi.check(L.vr_timing_read(r.handle, C.byref(tot_ms), C.byref(launches)), "vr_timing_read")
+        if len(slots) > 1:
+            # kernels of overlapping steps wait for each other's CUs, so their event intervals say nothing about the
+            # kernel: time it in a short pass of its own, one step after the other (outside the timed region)
+            capi.check(L.vr_set_timing(r.handle, 1), "vr_set_timing")
+            for _ in range(3):
+                step_no[0] = 0
+                step()
+                torch.cuda.synchronize()
+            capi.check(L.vr_set_timing(r.handle, 0), "vr_set_timing")
+            capi.check(L.vr_timing_read(r.handle, C.byref(tot_ms), C.byref(launches)), "vr_timing_read")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        rays = torch.tensor([float(plan.rays)], dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        return float(t.item()), float(rays.item()), tot_ms.value / max(1, launches.value), int(launches.value)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    main_plan = Plan(scaling, args.shard)
+    slots = [(r, main_plan.d_rgb, main_plan.d_stats, stream)]
+    for _ in range(1, args.in_flight):  # further slots, each with its own context (scratch), stream and output buffers
+        r2 = vr.Renderer(local_rank)
+        r2.upload_volume(data)
+        r2.build_kdt("AlwaysCenter")
+        r2.set_kernel(args.kernel)
+        slots.append((r2, torch.empty_like(main_plan.d_rgb), torch.zeros_like(main_plan.d_stats), torch.cuda.Stream()))
+    dt, rays_per_step, kernel_ms, launches = measure(main_plan, args.gather, slots)
 
-    stats = d_stats.cpu().numpy()
-    nodes_checked = int(stats[:, 0].sum())
-    errors = int(stats[:, 6].sum())
-    rays_per_step_rank = iso_count * W * (row_end - row_begin)
-    rays_total = torch.tensor([rays_per_step_rank], dtype=torch.float64, device=red_dev)
+    stats = main_plan.d_stats.cpu().numpy()
+    nodes_checked = int(stats[:, 0].sum()) if main_plan.rays else 0
+    errors = torch.tensor([float(stats[:, 6].sum()) if main_plan.rays else 0.0], dtype=torch.float64, device=red_dev)
     if world > 1:
-        dist.all_reduce(rays_total, op=dist.ReduceOp.SUM)
-    rays_per_step = float(rays_total.item())
+        dist.all_reduce(errors, op=dist.ReduceOp.SUM)
+    sweep_kernel = (not wide) and (args.kernel == 5 or (args.kernel == 0 and main_plan.iso_count >= 8))
+    info = None
+    if sweep_kernel and main_plan.rays:
+        si = capi.SweepInfo()
+        torch.cuda.synchronize()
+        if L.vr_sweep_info_read(r.handle, C.byref(si)) == capi.VR_OK and si.tick_end > si.tick_begin:
+            span = float(si.tick_end - si.tick_begin)
+            info = {"walks_per_launch": int(si.walks), "items_per_launch": int(si.items),
+                    "drain_frac": (si.tick_end - min(si.tick_queue_empty, si.tick_end)) / span,
+                    "kernel_span_ms_gpu_clock": span / 1e5}
+
+    extras = {}
+    if world > 1 and not args.no_extras:
+        for name, plan, gather in (("weak_scaling", Plan("weak", args.shard), False),
+                                   ("strong_scaling", Plan("strong", args.shard), False),
+                                   ("strong_with_gather", Plan("strong", args.shard), True)):
+            if (name == "weak_scaling" and scaling == "weak" and not args.gather) or \
+               (name == "strong_scaling" and scaling == "strong" and not args.gather) or \
+               (name == "strong_with_gather" and scaling == "strong" and args.gather):
+                continue  # that is the main figure
+            dt_x, rays_x, kms_x, _ = measure(plan, gather)
+            extras[name] = {"value": rays_x * args.steps / dt_x / 1e6, "unit": "Mrays/s", "ms_per_step": dt_x / args.steps * 1e3,
+                            "kernel_ms_rank0": kms_x, "sharding": plan.describe(), "gather": gather,
+                            "rays_per_step": int(rays_x)}
+            del plan
 
     if rank == 0:
-        kernel_ms = tot_ms.value / max(1, launches.value)
-        alg_bytes = 4.0 * nodes_checked + 3.0 * rays_per_step_rank
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
+        vol_name = {"skull": "Skull.vol", "c60": "C60.vol", "standin256": "256^3 stand-in", "gyroid1024": "1024^3 gyroid"}[args.volume]
+        workload = "%s_%dx%d_iso%d-%d_sweep" % (args.volume, W, H, I0, I0 + IN - 1)
+        kernel_name = ("vr_k_render_wide" if args.kernel in (1, 2, 3) else "vr_k_trace_wide") if wide else (
+            {0: "vr_k_sweep" if main_plan.iso_count >= 8 else "vr_k_trace", 4: "vr_k_trace", 5: "vr_k_sweep"}.get(args.kernel, "vr_k_render"))
+        alg_bytes = 4.0 * nodes_checked + 3.0 * main_plan.rays
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        counters, traffic, stale = (None, None, None)
+        if world == 1 and args.kernel == 0:
+            counters, traffic, stale = profile_counters(workload, kernel_name, kernel_ms)
         out = {
-            "metric": "Mrays/s on the %s iso sweep (iso %d..%d) at %dx%d" % (
-                {"skull": "Skull.vol", "c60": "C60.vol", "standin256": "256^3 stand-in",
-                 "gyroid1024": "1024^3 gyroid"}[args.volume], I0, I0 + IN - 1, W, H),
+            "metric": "Mrays/s on the %s iso sweep (iso %d..%d) at %dx%d" % (vol_name, I0, I0 + IN - 1, W, H),
             "value": rays_per_step * args.steps / dt / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -307,42 +403,56 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": what,
-            "config": {"workload": "%s_%dx%d_iso%d-%d_sweep" % (args.volume, W, H, I0, I0 + IN - 1),
+            "config": {"workload": workload,
                        "volume": "%s %dx%dx%d" % ((args.volume,) + tuple(data.resulution)),
                        "tree": "SlimKDT AlwaysCenter built on the GPU, %d nodes, depth %d" % (
                            build.number_of_nodes, build.layer_count),
                        "rays_per_step": int(rays_per_step),
-                       "sharding": "none" if world == 1 else (
-                           ("row-blocks" if args.shard == "rows" else "iso-blocks") if args.scaling == "strong" else
-                           "one sweep per rank"),
+                       "sharding": main_plan.describe(),
                        "gather": bool(args.gather and world > 1),
                        "kernel": "wide" if wide else capi.lib().vr_kernel_name(args.kernel).decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("vr_k_render_wide" if args.kernel in (1, 2, 3) else "vr_k_trace_wide") if wide else (
-                             {0: "vr_k_sweep" if IN >= 8 else "vr_k_trace", 4: "vr_k_trace", 5: "vr_k_sweep"}.get(
-                                 args.kernel, "vr_k_render")), "kernel_ms": kernel_ms, "launches_timed": int(launches.value),
+                         "hbm_traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and kernel_ms > 0 else None,
+                         "counters": counters, "counters_stale": stale,
+                         "kernel": kernel_name, "kernel_ms": kernel_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_launch": alg_bytes, "nodes_checked_per_launch": nodes_checked,
                          "measured_copy_GBps": copy_ceiling_gbps(torch),
-                         "note": ("algorithmic bytes = the reference's node reads (4 B x nodes_checked) + 3 B per pixel; the "
-                                  "kernels read far fewer nodes (resume traversal; the sweep kernel also shares traversals "
-                                  "between iso values), so frac prices the reference's work and can exceed 1 -- HBM itself "
-                                  "moves `traffic` bytes per launch"),
-                         "counters": profile_counters() if (args.volume == "skull" and W == 1024 and IN == 256) else None},
-            "errors": errors,
+                         "note": ("algorithmic bytes = the reference's node reads (4 B x nodes_checked) + 3 B per pixel, for "
+                                  "rank 0's launch; the kernels read far fewer nodes (resume traversal; the sweep kernel also "
+                                  "shares traversals between iso values), so frac prices the reference's work and can exceed "
+                                  "1 -- hbm_traffic_frac is what HBM itself moves against its peak (counter pass of this "
+                                  "workload; null when none is committed for it)")},
+            "errors": int(errors.item()),
             "steps_in_flight": args.in_flight,
         }
+        if info:
+            out["roofline"].update(info)
+        out.update(extras)
         if rehearsal:
             out["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
-        if args.volume != "skull" or W != 1024 or IN != 256:
-            out["roofline"]["traffic"] = None  # the committed counter pass is for the default workload only
         if wide:
             out["build_ms_gpu"] = build_ms  # the host builder and the CPU oracle cannot run at this size
-        elif not args.no_cpu_baseline and world == 1:
+        if world == 1 and not wide and IN * W * H * 3 <= (1 << 30):
+            # the sweep as the reference's caller gets it: frames in host memory (page-locked), src/main.zig:119-135
+            try:
+                buf = r.pinned_frames(IN, H, W)
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    r.renderSweep(pos, forw, up, W, H, 2.0, I0, IN, out=buf)
+                    best = min(best, time.perf_counter() - t0)
+                out["value_host_delivered"] = IN * W * H / best / 1e6
+                out["host_delivered_ms_per_step"] = best * 1e3
+                del buf
+            except capi.VrError as e:
+                out["value_host_delivered"] = None
+                out["host_delivered_error"] = str(e)
+        if not wide and not args.no_cpu_baseline and world == 1:
             kdt = vr.SlimKDT.newHeursiticPartition(data, "AlwaysCenter")  # host copy for the CPU legs
             out["cpu_baseline"] = cpu_baseline(kdt, pos, forw, up, W, I0, IN)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]

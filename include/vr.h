@@ -292,6 +292,19 @@ int vr_sync(vr_ctx *ctx);
 int vr_set_timing(vr_ctx *ctx, int enabled);
 int vr_timing_read(vr_ctx *ctx, double *total_ms_out, uint32_t *launches_out);
 
+/* What the sweep kernel reports about its last launch on this context through vr_render_device / vr_render_sweep
+ * (measurement only, no counterpart in the reference): the traversals it ran (one serves every iso value that
+ * cannot change a range test on its way), its work items, and when -- in ticks of the GPU's 100 MHz clock -- the
+ * first wave started, the first wave found the queue empty, and the last wave ended.  Waits for the context's own
+ * stream; a caller that rendered on a stream of its own synchronises that one first.  VR_ESTATE when no
+ * sweep-kernel launch has used the context's scratch yet. */
+typedef struct vr_sweep_info {
+    uint64_t walks;
+    uint64_t items;
+    uint64_t tick_begin, tick_queue_empty, tick_end;
+} vr_sweep_info;
+int vr_sweep_info_read(vr_ctx *ctx, vr_sweep_info *out);
+
 /* Traversal kernel selection: 0 = default (fastest verified: from 8 iso values on the sweep
  * kernel, which traces a ray once per interval of iso values that cannot change the outcome of any
  * density-range test and gives every iso value of the interval that result), other values name the

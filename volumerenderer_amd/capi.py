@@ -39,7 +39,7 @@ HEURISTICS = {
 EXPORTS = [
     "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_host_check_kdt_wide", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_alloc_host", "vr_free_host", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
     "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_upload_kdt_wide", "vr_download_kdt_wide", "vr_render",
-    "vr_render_sweep", "vr_render_device", "vr_render_device_noalloc", "vr_render_device_bands", "vr_mgpu_render_sweep", "vr_sync", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
+    "vr_render_sweep", "vr_render_device", "vr_render_device_noalloc", "vr_render_device_bands", "vr_mgpu_render_sweep", "vr_sync", "vr_sweep_info_read", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
 ]
 
@@ -61,6 +61,11 @@ class RenderStats(C.Structure):
 class View(C.Structure):
     _fields_ = [("src", C.c_float * 3), ("forw", C.c_float * 3), ("up", C.c_float * 3),
                 ("viewport_width", C.c_float), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class SweepInfo(C.Structure):
+    _fields_ = [("walks", C.c_uint64), ("items", C.c_uint64), ("tick_begin", C.c_uint64),
+                ("tick_queue_empty", C.c_uint64), ("tick_end", C.c_uint64)]
 
 
 class Taps(C.Structure):
@@ -128,6 +133,7 @@ def lib():
     L.vr_mgpu_render_sweep.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(View), C.c_uint32, C.c_uint32, C.c_int, vp,
                                        C.POINTER(RenderStats)]
     L.vr_sync.argtypes = [vp]
+    L.vr_sweep_info_read.argtypes = [vp, C.POINTER(SweepInfo)]
     L.vr_set_timing.argtypes = [vp, C.c_int]
     L.vr_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.vr_set_kernel.argtypes = [vp, C.c_int]

@@ -46,6 +46,7 @@ struct vr_ctx {
     size_t stats_cap = 0;
     void *d_tap[4] = { nullptr, nullptr, nullptr, nullptr };
     size_t tap_cap[4] = { 0, 0, 0, 0 };
+    size_t info_off = 0; /* where the last sweep-kernel launch in d_work left its report; 0 = none yet */
     /* options */
     int variant = VR_KERNEL_DEFAULT;
     int timing = 0;
@@ -433,6 +434,8 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
                                 row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1));
     if (timing) c->ev_used += 2;
+    if (!fixed_scratch && !c->wide && (variant == VR_KERNEL_SWEEP || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u)))
+        c->info_off = vr_pipeline_info_offset(view->width, row_end - row_begin);
     return VR_OK;
 }
 
@@ -619,6 +622,16 @@ int vr_sync(vr_ctx *c)
     if (!c) return VR_EARG;
     VR_HIP(hipSetDevice(c->device));
     VR_HIP(hipStreamSynchronize(c->stream));
+    return VR_OK;
+}
+
+int vr_sweep_info_read(vr_ctx *c, vr_sweep_info *out)
+{
+    if (!c || !out) return VR_EARG;
+    if (!c->d_work || !c->info_off) return VR_ESTATE;
+    VR_HIP(hipSetDevice(c->device));
+    VR_HIP(hipStreamSynchronize(c->stream));
+    VR_HIP(hipMemcpy(out, (const char *)c->d_work + c->info_off, sizeof(*out), hipMemcpyDeviceToHost));
     return VR_OK;
 }
 

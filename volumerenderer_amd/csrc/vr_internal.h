@@ -31,6 +31,9 @@ enum {
 /* Device scratch the pipeline variant needs for one call (ray list, tile offsets, queue heads). */
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count);
 
+/* Byte offset, inside the pipeline workspace of a call, of the sweep kernel's 40-byte report (vr_sweep_info). */
+size_t vr_pipeline_info_offset(uint32_t width, uint32_t n_rows);
+
 /* Enqueues the kernels that render rows [row_begin,row_end) of iso_count frames.  d_nodes_raw is the
  * reference's SlimNode array, d_nodes_prepared the flattened form of vr_host_prepare_kdt.  The
  * dominant traversal kernel is bracketed by ev_begin / ev_end when they are not null. */

@@ -311,7 +311,12 @@ __global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, 
         if (i < e) count[i] = run + x - c;
         run += __shfl(x, 63, 64);
     }
-    if (threadIdx.x == 0) *n_active_out = total;
+    if (threadIdx.x == 0) {
+        *n_active_out = total;
+        /* the sweep kernel's report (vr_sweep_info, 64 bytes behind the ray count): walks, items, first / queue-empty / last tick */
+        unsigned long long *info = (unsigned long long *)(n_active_out + 16);
+        info[0] = 0; info[1] = 0; info[2] = ~0ull; info[3] = ~0ull; info[4] = 0;
+    }
     /* the small set-up work of a call rides along: empty queues, and the per-iso counters at their starting
      * values (every pixel that never enters the volume is OOB in every frame) */
     for (uint32_t k = threadIdx.x; k < iso_count; k += 1024u) {
@@ -717,7 +722,8 @@ constexpr uint32_t kSweepCounters = 5; /* hit, miss, moves, escape help, errors 
 
 __host__ __device__ __forceinline__ uint32_t sweep_stat_words(uint32_t iso_count)
 {
-    return (2u + kSweepCounters) * (iso_count + 1u) + ((2u + kSweepCounters) * (iso_count + 1u) & 1u);
+    const uint32_t words = (2u + kSweepCounters) * (iso_count + 1u) + 1u; /* + the block's traversal count */
+    return words + (words & 1u);
 }
 
 template <bool TAPS>
@@ -762,6 +768,12 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     unsigned long long d_exh = 0, d_rexh = 0;
     uint32_t d_lane_traces = 0, d_lane_emit = 0;
 #endif
+    /* the kernel's report on itself (read back with vr_sweep_info_read): traversals done, and the 100 MHz ticks at
+     * which the first wave started, the first wave found the queue empty, and the last wave ended */
+    unsigned long long *info = (unsigned long long *)(n_active_ptr + 16);
+    const unsigned long long tick_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tick_empty = 0;
+    uint32_t n_walks = 0;
     VrLane L;
     WaveChunk chunk;
     VrIsoUpper track;
@@ -793,6 +805,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 popping = false;
             }
             exhausted = chunk.exhausted();
+            if (exhausted && !tick_empty) tick_empty = __builtin_amdgcn_s_memrealtime();
 #ifdef VR_DIAG
             if (exhausted && !d_exh) { d_exh = __builtin_amdgcn_s_memtime(); d_rexh = __builtin_amdgcn_s_memrealtime(); }
 #endif
@@ -862,6 +875,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
             if (popping && !done) popping = !vr_lane_pop(L, stack, kSweepPopTrips);
 
             if (done) {
+                n_walks++;
                 /* ---- the traversal stands for every iso value from `iso` to `e` ---- */
                 const uint32_t e = track.upper < iso_last ? track.upper : iso_last;
                 const uint32_t k0 = iso - iso_begin, k1 = e + 1u - iso_begin;
@@ -922,8 +936,23 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
         }
     }
 #endif
+    {
+        const uint32_t w_walks = wave_sum(n_walks);
+        if (lane == 0) {
+            atomicAdd(&s_cnt[kSweepCounters * n_k], w_walks); /* the word behind the counter arrays */
+            if ((threadIdx.x >> 6) == 0u) { /* one wave per block reports the times */
+                atomicMin(&info[2], tick_begin);
+                if (tick_empty) atomicMin(&info[3], tick_empty);
+            }
+        }
+    }
     /* ---- per-iso counters: prefix sums of the difference arrays, then one atomic per iso value and counter ---- */
     __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&info[0], (unsigned long long)s_cnt[kSweepCounters * n_k]);
+        if (blockIdx.x == 0) info[1] = n_items;
+        atomicMax(&info[4], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
     if (threadIdx.x < kSweepCounters) {
         uint32_t *c = s_cnt + threadIdx.x * n_k;
         uint32_t run = 0;
@@ -1249,6 +1278,14 @@ void *vr_noalloc_scratch(int device)
     if (device < 0 || device >= kMaxDevices) return nullptr;
     std::lock_guard<std::mutex> lock(g_setup_mutex);
     return g_setup_done[device] ? g_scratch_ptr[device] : nullptr;
+}
+
+size_t vr_pipeline_info_offset(uint32_t width, uint32_t n_rows)
+{
+    const size_t n_pix = (size_t)width * n_rows;
+    const size_t n_blocks = padded_tiles(width, n_rows) / (kSuper * kSuper);
+    return ((n_pix * sizeof(float4) + 255) & ~(size_t)255) + ((n_pix * sizeof(uint32_t) + 255) & ~(size_t)255) +
+           ((n_blocks * sizeof(uint32_t) + 255) & ~(size_t)255) + 64u;
 }
 
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count)
