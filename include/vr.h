@@ -269,6 +269,24 @@ int vr_render_device_noalloc(vr_ctx *ctx, const vr_view *view, uint32_t iso_begi
                              uint32_t row_begin, uint32_t row_end, void *d_rgb24, void *d_stats,
                              const vr_taps *d_taps, void *stream);
 
+/* ---- trilinear refinement ---------------------------------------------------------------- */
+
+/* raytrace.trilerp (src/raytrace.zig:257-291) on the GPU, bit for bit (strict f32, the reference's operation
+ * order): d_in holds n records of 17 floats -- x, y, z, x0, x1, y0, y1, z0, z1, values[8] (v000, v100, v010, v110,
+ * v001, v101, v011, v111) -- and d_out receives n results.  Device pointers; asynchronous on `stream`
+ * (NULL = the context's own). */
+int vr_trilerp_device(vr_ctx *ctx, const float *d_in, uint64_t n, float *d_out, void *stream);
+
+/* The refinement the reference only sketches: trilerpTrace (src/raytrace.zig:295-304) fetches the hit cell's 8
+ * corner densities (Data.getCornerDens, src/Data.zig:102-114) and stops there.  For every pixel whose ray hit, this
+ * post-pass over the taps of vr_render_device (same view, same rows, n_frames frames) evaluates trilerp at the hit
+ * point src + dir * t inside the hit cell and stores the interpolated density; 0 for the other pixels.  It is the
+ * one step of the path that reads voxels at render time, so the context needs both the volume
+ * (vr_upload_volume) and its tree.  Nothing in the reference pins the result beyond trilerp and getCornerDens
+ * themselves: parity unpinned. */
+int vr_refine_device(vr_ctx *ctx, const vr_view *view, uint32_t n_frames, uint32_t row_begin, uint32_t row_end,
+                     const uint32_t *d_cell_flag, const float *d_t, float *d_density, void *stream);
+
 /* One host thread driving several contexts -- normally one per GPU of the node, each holding the same tree
  * (contexts on one device work too).  The iso loop of src/main.zig:111-138 is split over the contexts with no
  * exchange between them: VR_SHARD_ISO gives context i a contiguous block of the iso values (whole frames),

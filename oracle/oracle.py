@@ -166,3 +166,35 @@ def render(nodes, root_dim, src, forw, up, width, height, viewport_width, iso, r
     if rc != 0:
         raise RuntimeError("vro_render_rows failed: %d" % rc)
     return {"rgb": rgb, "stats": st, "cell_flag": cf, "t": tt, "checked": ck, "node": nd}
+
+
+def trilerp_batch(points):
+    """trilerp (src/raytrace.zig:257-291) on an [n, 17] float32 array of (x, y, z, x0, x1, y0, y1, z0, z1, values[8])."""
+    L = lib()
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    assert pts.ndim == 2 and pts.shape[1] == 17
+    out = np.zeros(len(pts), dtype=np.float32)
+    L.vro_trilerp_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.vro_trilerp_batch.restype = None
+    L.vro_trilerp_batch(pts.ctypes.data, len(pts), out.ctypes.data)
+    return out
+
+
+def refine(vox, src, forw, up, width, height, viewport_width, cell_flag, t, rows=None, wide=False):
+    """Density trilerp gives at every hit point inside its hit cell (0 where the ray did not hit); parity unpinned
+    beyond trilerp and getCornerDens (src/Data.zig:102-114)."""
+    L = lib(wide)
+    vox = np.ascontiguousarray(vox, dtype=np.uint8)
+    res = (C.c_uint32 * 3)(*vox.shape)
+    cf = np.ascontiguousarray(cell_flag, dtype=np.uint32)
+    tt = np.ascontiguousarray(t, dtype=np.float32)
+    out = np.zeros((height, width), dtype=np.float32)
+    r0, r1 = (0, height) if rows is None else rows
+    L.vro_refine_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                  C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.vro_refine_rows(vox.ctypes.data, res, _f3(src), _f3(forw), _f3(up), width, height, float(viewport_width), r0, r1,
+                           cf.ctypes.data, tt.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("vro_refine_rows failed: %d" % rc)
+    return out

@@ -237,3 +237,19 @@ extern "C" int vr_emu_wide(const uint32_t *nodes, uint64_t n_slots, const uint16
         }
     return 0;
 }
+
+#include "../../volumerenderer_amd/csrc/vr_trilerp.h"
+
+/* the library's trilerp and corner fetch on the CPU: n records of 17 floats in, n densities out */
+extern "C" void vr_emu_trilerp(const float *in, uint64_t n, float *out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        const float *p = in + i * 17;
+        out[i] = vr_trilerp(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p + 9);
+    }
+}
+
+extern "C" void vr_emu_corner_dens(const uint8_t *vox, uint32_t ry, uint32_t rz, uint32_t cx, uint32_t cy, uint32_t cz, float out[8])
+{
+    vr_corner_dens(vox, ry, rz, cx, cy, cz, out);
+}

@@ -5,4 +5,4 @@ name=$1; shift
 cd "$(dirname "$0")/../volumerenderer_amd/csrc"
 mkdir -p ../tune
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt \
-  -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-result -shared "$@" -o ../tune/libvr_$name.so vr_kernels.hip vr_build.hip vr_capi.hip vr_host.cpp vr_image_io.cpp
+  -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-result -shared "$@" -o ../tune/libvr_$name.so vr_kernels.hip vr_build.hip vr_refine.hip vr_capi.hip vr_host.cpp vr_image_io.cpp

@@ -39,7 +39,7 @@ HEURISTICS = {
 EXPORTS = [
     "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_host_check_kdt_wide", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_alloc_host", "vr_free_host", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
     "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_upload_kdt_wide", "vr_download_kdt_wide", "vr_render",
-    "vr_render_sweep", "vr_render_device", "vr_render_device_noalloc", "vr_render_device_bands", "vr_mgpu_render_sweep", "vr_sync", "vr_sweep_info_read", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
+    "vr_render_sweep", "vr_render_device", "vr_render_device_noalloc", "vr_render_device_bands", "vr_mgpu_render_sweep", "vr_trilerp_device", "vr_refine_device", "vr_sync", "vr_sweep_info_read", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
 ]
 
@@ -132,6 +132,8 @@ def lib():
                                          C.c_uint32, vp, vp, C.POINTER(Taps), vp]
     L.vr_mgpu_render_sweep.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(View), C.c_uint32, C.c_uint32, C.c_int, vp,
                                        C.POINTER(RenderStats)]
+    L.vr_trilerp_device.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    L.vr_refine_device.argtypes = [vp, C.POINTER(View), C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.vr_sync.argtypes = [vp]
     L.vr_sweep_info_read.argtypes = [vp, C.POINTER(SweepInfo)]
     L.vr_set_timing.argtypes = [vp, C.c_int]

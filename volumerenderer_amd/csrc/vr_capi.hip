@@ -617,6 +617,31 @@ int vr_mgpu_render_sweep(vr_ctx *const *ctxs, uint32_t n_ctx, const vr_view *vie
     return rc;
 }
 
+int vr_trilerp_device(vr_ctx *c, const float *d_in, uint64_t n, float *d_out, void *stream)
+{
+    if (!c || (n && (!d_in || !d_out))) return VR_EARG;
+    VR_HIP(hipSetDevice(c->device));
+    VR_HIP(vr_launch_trilerp(stream ? (hipStream_t)stream : c->stream, d_in, n, d_out));
+    return VR_OK;
+}
+
+int vr_refine_device(vr_ctx *c, const vr_view *view, uint32_t n_frames, uint32_t row_begin, uint32_t row_end,
+                     const uint32_t *d_cell_flag, const float *d_t, float *d_density, void *stream)
+{
+    if (!c || !d_cell_flag || !d_t || !d_density || n_frames == 0) return VR_EARG;
+    int rc = check_view(view);
+    if (rc != VR_OK) return rc;
+    if (row_begin >= row_end || row_end > view->height) return VR_EARG;
+    if (!c->d_vox || !c->d_nodes) return VR_ESTATE; /* the corner voxels come from the uploaded volume */
+    for (int a = 0; a < 3; a++)
+        if (c->root_dim[a] + 1u != c->res[a]) return VR_ESTATE; /* the tree on the context is of another volume */
+    VR_HIP(hipSetDevice(c->device));
+    const VrViewK k = make_view(c, view);
+    VR_HIP(vr_launch_refine(stream ? (hipStream_t)stream : c->stream, k, c->wide, c->d_vox, c->res[1], c->res[2], row_begin,
+                            row_end - row_begin, n_frames, d_cell_flag, d_t, d_density));
+    return VR_OK;
+}
+
 int vr_sync(vr_ctx *c)
 {
     if (!c) return VR_EARG;

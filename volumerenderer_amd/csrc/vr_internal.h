@@ -77,4 +77,11 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
                                  hipEvent_t ev_begin, hipEvent_t ev_end);
 
+
+/* Trilinear refinement (vr_refine.hip): trilerp on n packed argument records, and the post-pass over the hit taps. */
+hipError_t vr_launch_trilerp(hipStream_t stream, const float *d_in, uint64_t n, float *d_out);
+hipError_t vr_launch_refine(hipStream_t stream, const VrViewK &view, bool wide, const uint8_t *d_vox, uint32_t ry, uint32_t rz,
+                            uint32_t row_begin, uint32_t n_rows, uint32_t n_frames, const uint32_t *d_cell_flag, const float *d_t,
+                            float *d_density);
+
 #endif
