@@ -287,6 +287,44 @@ int vr_trilerp_device(vr_ctx *ctx, const float *d_in, uint64_t n, float *d_out, 
 int vr_refine_device(vr_ctx *ctx, const vr_view *view, uint32_t n_frames, uint32_t row_begin, uint32_t row_end,
                      const uint32_t *d_cell_flag, const float *d_t, float *d_density, void *stream);
 
+/* ---- one ray, step by step ------------------------------------------------------------------ */
+
+/* The reference's per-ray debug print (traceRay compiled with dbp = true, src/raytrace.zig:133-146, 164-198) as
+ * data: one record per iteration of its loop, in order. */
+#define VR_STEP_ZOOM 0u /* "ZOOM!" :189-192 */
+#define VR_STEP_HIT 1u  /* "HIT!"  :179-187 */
+#define VR_STEP_MOVE 2u /* "MOVE!" :197-205 */
+typedef struct vr_ray_step {
+    float t;           /* at the top of the iteration (:167)                      */
+    float p[3];        /* ray.point(t)                                            */
+    uint32_t node;     /* st.node_idx                                             */
+    uint32_t size;     /* st.node_space.size()                                    */
+    uint8_t min, max;  /* kdt.nodes[node].density_range                           */
+    uint8_t isoval;
+    uint8_t action;    /* VR_STEP_*                                               */
+} vr_ray_step;
+typedef struct vr_ray_report {
+    float origin[3], dir[3]; /* the ray of the pixel (src/raytrace.zig:41-45)                                  */
+    float t_entry;           /* t after the skip into the volume (:127-131)                                    */
+    float t_final;           /* RayRes.t (0 for an OOB ray)                                                    */
+    uint32_t flag;           /* VR_FLAG_*                                                                      */
+    uint32_t n_steps;        /* iterations the ray took = RayRes.checked_nodes; may exceed the records stored  */
+    uint32_t n_stored;       /* records written to steps_out (at most cap)                                     */
+} vr_ray_report;
+
+/* Traces the ray of pixel (xi, yi) of `view` for one iso value on the GPU with the reference's own loop (restart at
+ * the root after every MOVE, every node read from the SlimNode array as uploaded) and returns its iterations.
+ * Host pointers; steps_out may be NULL with cap = 0 to get the report alone.  Trees of vr_upload_kdt / vr_build_kdt
+ * on volumes within the reference's range (VR_ESTATE for wide trees).  Synchronous. */
+int vr_trace_ray(vr_ctx *ctx, const vr_view *view, uint8_t isoval, uint32_t xi, uint32_t yi, vr_ray_step *steps_out,
+                 uint32_t cap, vr_ray_report *report_out);
+
+/* Writes a trace in the layout of the reference's debug print ("### NEW RAY ###", then per iteration
+ * "t=...  r=(...)" / "node=...   size=...   iso=[min-max] v iso" / "  res: ZOOM!|HIT!|MOVE!") to `path`
+ * (NULL = stderr).  vr_render and vr_render_sweep do this by themselves for the pixel named by the environment
+ * variable VR_TRACE_RAY=x,y (first iso value of the call, to stderr). */
+int vr_print_ray_trace(const vr_ray_report *report, const vr_ray_step *steps, const char *path);
+
 /* One host thread driving several contexts -- normally one per GPU of the node, each holding the same tree
  * (contexts on one device work too).  The iso loop of src/main.zig:111-138 is split over the contexts with no
  * exchange between them: VR_SHARD_ISO gives context i a contiguous block of the iso values (whole frames),

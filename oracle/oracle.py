@@ -198,3 +198,30 @@ def refine(vox, src, forw, up, width, height, viewport_width, cell_flag, t, rows
     if rc != 0:
         raise RuntimeError("vro_refine_rows failed: %d" % rc)
     return out
+
+
+class RayStep(C.Structure):
+    _fields_ = [("t", C.c_float), ("p", C.c_float * 3), ("node", C.c_uint32), ("size", C.c_uint32), ("min", C.c_uint8),
+                ("max", C.c_uint8), ("isoval", C.c_uint8), ("action", C.c_uint8)]
+
+
+class RayReport(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("dir", C.c_float * 3), ("t_entry", C.c_float), ("t_final", C.c_float),
+                ("flag", C.c_uint32), ("n_steps", C.c_uint32), ("n_stored", C.c_uint32)]
+
+
+def trace_ray(nodes, root_dim, src, forw, up, width, height, viewport_width, iso, xi, yi, cap=1 << 16):
+    """traceRay of one pixel with every loop iteration recorded (the reference's dbp print as data): (report, steps)."""
+    L = lib()
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+    rd = (C.c_uint8 * 3)(*[int(x) for x in root_dim])
+    steps = (RayStep * cap)()
+    rep = RayReport()
+    L.vro_trace_ray.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                C.c_uint32, C.c_uint32, C.c_float, C.c_uint8, C.c_uint32, C.c_uint32, C.POINTER(RayStep),
+                                C.c_uint32, C.POINTER(RayReport)]
+    rc = L.vro_trace_ray(nodes.ctypes.data, rd, _f3(src), _f3(forw), _f3(up), width, height, float(viewport_width), int(iso),
+                         int(xi), int(yi), steps, cap, C.byref(rep))
+    if rc != 0:
+        raise RuntimeError("vro_trace_ray failed: %d" % rc)
+    return rep, np.frombuffer(steps, dtype=np.uint8).reshape(cap, C.sizeof(RayStep))[: rep.n_stored].copy()

@@ -389,8 +389,28 @@ typedef struct {
     uint32_t moves;
 } ray_res;
 
+/* what the reference's debug print shows of every loop iteration (dbp = true, src/raytrace.zig:164-198) */
+typedef struct {
+    float t, p[3];
+    uint32_t node, size;
+    uint8_t min, max, isoval, action; /* action: 0 ZOOM, 1 HIT, 2 MOVE */
+} vro_ray_step;
+typedef struct { vro_ray_step *out; uint32_t cap, n; } step_rec;
+
+static void rec_step(step_rec *rec, float t, vec3 p, uint32_t node, uint32_t size, uint32_t word, uint8_t iso, uint8_t action)
+{
+    if (!rec) return;
+    if (rec->n < rec->cap) {
+        vro_ray_step *s = &rec->out[rec->n];
+        s->t = t; s->p[0] = p.x; s->p[1] = p.y; s->p[2] = p.z;
+        s->node = node; s->size = size;
+        s->min = NODE_MIN(word); s->max = NODE_MAX(word); s->isoval = iso; s->action = action;
+    }
+    rec->n++;
+}
+
 /* src/raytrace.zig:117-255 traceRay with the SpaceTracker of src/SlimKDT.zig:48-115 inlined */
-static ray_res trace_ray(vec3 o, vec3 d, const uint32_t *nodes, const coord_t root_dim[3], uint8_t iso)
+static ray_res trace_ray_rec(vec3 o, vec3 d, const uint32_t *nodes, const coord_t root_dim[3], uint8_t iso, step_rec *rec, float *t_entry)
 {
     ray_res res;
     memset(&res, 0, sizeof res);
@@ -413,6 +433,7 @@ static ray_res trace_ray(vec3 o, vec3 d, const uint32_t *nodes, const coord_t ro
     t = fmaxf(t, plane_ray_intersect(1, box_plane_offset(space, 3 - doy), o, d));
     t = fmaxf(t, plane_ray_intersect(2, box_plane_offset(space, 5 - doz), o, d));
     t += 0.001f;
+    if (t_entry) *t_entry = t;
 
     if (!box_contains_float(space, ray_point(o, d, t))) { /* :148-156 */
         res.oob = 1;
@@ -426,6 +447,8 @@ static ray_res trace_ray(vec3 o, vec3 d, const uint32_t *nodes, const coord_t ro
         coord_t cell[3] = { (coord_t)p.x, (coord_t)p.y, (coord_t)p.z }; /* :163, src/geo.zig:74-81 */
         uint32_t n = nodes[idx];
         range8 dr = { NODE_MIN(n), NODE_MAX(n) };
+        rec_step(rec, t, p, idx, box_size(space), n, iso,
+                 range_contains_inclusive(dr, iso) ? (box_size(space) == 1 ? 1 : 0) : 2); /* the print of :164-174 */
         if (range_contains_inclusive(dr, iso)) { /* :177 */
             if (box_size(space) == 1) {          /* :178-187 */
                 res.t = t;
@@ -474,6 +497,11 @@ static ray_res trace_ray(vec3 o, vec3 d, const uint32_t *nodes, const coord_t ro
     res.enter_vol_t = enter_vol_t;
     res.checked_nodes = checked;
     return res;
+}
+
+static ray_res trace_ray(vec3 o, vec3 d, const uint32_t *nodes, const coord_t root_dim[3], uint8_t iso)
+{
+    return trace_ray_rec(o, d, nodes, root_dim, iso, NULL, NULL);
 }
 
 typedef struct {
@@ -660,3 +688,35 @@ int vro_refine_rows(const uint8_t *vox, const uint32_t res[3], const float src[3
     }
     return VRO_OK;
 }
+
+/* One ray of renderImage's pixel grid (src/raytrace.zig:41-45) traced with every loop iteration recorded: what the
+ * reference prints with dbp = true.  report = origin[3], dir[3], t_entry, t_final, then flag, n_steps, n_stored. */
+typedef struct { float origin[3], dir[3], t_entry, t_final; uint32_t flag, n_steps, n_stored; } vro_ray_report;
+
+#ifndef VRO_WIDE
+int vro_trace_ray(const uint32_t *nodes, const coord_t root_dim[3], const float src[3], const float forw[3], const float up[3],
+                  uint32_t width, uint32_t height, float viewport_width, uint8_t iso, uint32_t xi, uint32_t yi,
+                  vro_ray_step *steps, uint32_t cap, vro_ray_report *report)
+{
+    if (!nodes || !root_dim || !src || !forw || !up || !report || !width || !height || xi >= width || yi >= height) return VRO_EARG;
+    vec3 o = v_new(src[0], src[1], src[2]);
+    vec3 f = v_new(forw[0], forw[1], forw[2]);
+    vec3 u = v_new(up[0], up[1], up[2]);
+    float pixel_size = viewport_width / (float)width;
+    vec3 right = v_cross(f, u);
+    float yf = ((float)yi - (float)(height / 2)) * pixel_size;
+    float xf = ((float)xi - (float)(width / 2)) * pixel_size;
+    vec3 dir = v_norm(v_add(f, v_add(v_scale(u, yf), v_scale(right, xf))));
+    step_rec rec = { steps, cap, 0 };
+    float t_entry = 0.0f;
+    ray_res r = trace_ray_rec(o, dir, nodes, root_dim, iso, &rec, &t_entry);
+    report->origin[0] = o.x; report->origin[1] = o.y; report->origin[2] = o.z;
+    report->dir[0] = dir.x; report->dir[1] = dir.y; report->dir[2] = dir.z;
+    report->t_entry = t_entry;
+    report->t_final = r.oob ? 0.0f : r.t;
+    report->flag = r.oob ? VRO_FLAG_OOB : (r.hit ? VRO_FLAG_HIT : VRO_FLAG_MISS);
+    report->n_steps = rec.n;
+    report->n_stored = rec.n < cap ? rec.n : cap;
+    return VRO_OK;
+}
+#endif

@@ -39,7 +39,7 @@ HEURISTICS = {
 EXPORTS = [
     "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_host_check_kdt_wide", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_alloc_host", "vr_free_host", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
     "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_upload_kdt_wide", "vr_download_kdt_wide", "vr_render",
-    "vr_render_sweep", "vr_render_device", "vr_render_device_noalloc", "vr_render_device_bands", "vr_mgpu_render_sweep", "vr_trilerp_device", "vr_refine_device", "vr_sync", "vr_sweep_info_read", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
+    "vr_render_sweep", "vr_render_device", "vr_render_device_noalloc", "vr_render_device_bands", "vr_mgpu_render_sweep", "vr_trace_ray", "vr_print_ray_trace", "vr_trilerp_device", "vr_refine_device", "vr_sync", "vr_sweep_info_read", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
 ]
 
@@ -66,6 +66,16 @@ class View(C.Structure):
 class SweepInfo(C.Structure):
     _fields_ = [("walks", C.c_uint64), ("items", C.c_uint64), ("tick_begin", C.c_uint64),
                 ("tick_queue_empty", C.c_uint64), ("tick_end", C.c_uint64)]
+
+
+class RayStep(C.Structure):
+    _fields_ = [("t", C.c_float), ("p", C.c_float * 3), ("node", C.c_uint32), ("size", C.c_uint32), ("min", C.c_uint8),
+                ("max", C.c_uint8), ("isoval", C.c_uint8), ("action", C.c_uint8)]
+
+
+class RayReport(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("dir", C.c_float * 3), ("t_entry", C.c_float), ("t_final", C.c_float),
+                ("flag", C.c_uint32), ("n_steps", C.c_uint32), ("n_stored", C.c_uint32)]
 
 
 class Taps(C.Structure):
@@ -132,6 +142,9 @@ def lib():
                                          C.c_uint32, vp, vp, C.POINTER(Taps), vp]
     L.vr_mgpu_render_sweep.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(View), C.c_uint32, C.c_uint32, C.c_int, vp,
                                        C.POINTER(RenderStats)]
+    L.vr_trace_ray.argtypes = [vp, C.POINTER(View), C.c_uint8, C.c_uint32, C.c_uint32, C.POINTER(RayStep), C.c_uint32,
+                               C.POINTER(RayReport)]
+    L.vr_print_ray_trace.argtypes = [C.POINTER(RayReport), C.POINTER(RayStep), C.c_char_p]
     L.vr_trilerp_device.argtypes = [vp, vp, C.c_uint64, vp, vp]
     L.vr_refine_device.argtypes = [vp, C.POINTER(View), C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.vr_sync.argtypes = [vp]

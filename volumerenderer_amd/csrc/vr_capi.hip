@@ -4,6 +4,7 @@
  * stand in for raytrace.renderImage (src/raytrace.zig:11-106) and the iso loop of the reference
  * driver (src/main.zig:111-138).
  */
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -469,8 +470,33 @@ int vr_render_device_noalloc(vr_ctx *c, const vr_view *view, uint32_t iso_begin,
                          VR_NOALLOC_SCRATCH_BYTES);
 }
 
+/* VR_TRACE_RAY=x,y in the environment: the reference's per-ray debug print (traceRay with dbp = true) for that pixel
+ * and the first iso value of the call, to stderr */
+static void trace_ray_from_env(vr_ctx *c, const vr_view *view, uint32_t iso)
+{
+    const char *env = std::getenv("VR_TRACE_RAY");
+    if (!env || !*env || c->wide) return;
+    unsigned x = 0, y = 0;
+    if (std::sscanf(env, "%u,%u", &x, &y) != 2 || x >= view->width || y >= view->height) return;
+    const uint32_t cap = 1u << 16;
+    std::vector<vr_ray_step> steps(cap);
+    vr_ray_report rep;
+    if (vr_trace_ray(c, view, (uint8_t)iso, x, y, steps.data(), cap, &rep) == VR_OK) (void)vr_print_ray_trace(&rep, steps.data(), nullptr);
+}
+
+static int render_sweep(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint8_t *rgb24_out,
+                        vr_render_stats *stats_out, const vr_taps *taps);
+
 int vr_render_sweep(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint8_t *rgb24_out,
                     vr_render_stats *stats_out, const vr_taps *taps)
+{
+    const int rc = render_sweep(c, view, iso_begin, iso_count, rgb24_out, stats_out, taps);
+    if (rc == VR_OK) trace_ray_from_env(c, view, iso_begin);
+    return rc;
+}
+
+static int render_sweep(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint8_t *rgb24_out,
+                        vr_render_stats *stats_out, const vr_taps *taps)
 {
     if (!c || !rgb24_out) return VR_EARG;
     int rc = check_view(view);
@@ -615,6 +641,30 @@ int vr_mgpu_render_sweep(vr_ctx *const *ctxs, uint32_t n_ctx, const vr_view *vie
             }
     }
     return rc;
+}
+
+int vr_trace_ray(vr_ctx *c, const vr_view *view, uint8_t isoval, uint32_t xi, uint32_t yi, vr_ray_step *steps_out, uint32_t cap,
+                 vr_ray_report *report_out)
+{
+    if (!c || !report_out || (cap && !steps_out)) return VR_EARG;
+    int rc = check_view(view);
+    if (rc != VR_OK) return rc;
+    if (xi >= view->width || yi >= view->height) return VR_EARG;
+    if (!c->d_nodes || c->wide) return VR_ESTATE;
+    VR_HIP(hipSetDevice(c->device));
+    const VrViewK k = make_view(c, view);
+    vr_ray_step *d_steps = nullptr;
+    vr_ray_report *d_report = nullptr;
+    hipError_t e = hipMalloc((void **)&d_report, sizeof(vr_ray_report));
+    if (e == hipSuccess && cap) e = hipMalloc((void **)&d_steps, sizeof(vr_ray_step) * (size_t)cap);
+    if (e == hipSuccess) e = vr_launch_trace_ray(c->stream, k, c->d_nodes, isoval, xi, yi, d_steps, cap, d_report);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(report_out, d_report, sizeof(vr_ray_report), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && cap && report_out->n_stored)
+        e = hipMemcpy(steps_out, d_steps, sizeof(vr_ray_step) * (size_t)report_out->n_stored, hipMemcpyDeviceToHost);
+    if (d_steps) (void)hipFree(d_steps);
+    if (d_report) (void)hipFree(d_report);
+    return e == hipSuccess ? VR_OK : VR_EHIP_BASE - (int)e;
 }
 
 int vr_trilerp_device(vr_ctx *c, const float *d_in, uint64_t n, float *d_out, void *stream)

@@ -469,3 +469,26 @@ int vr_host_check_kdt_wide(const uint32_t *nodes, uint64_t n_slots, const uint16
 void vr_free(void *p) { std::free(p); }
 
 } // extern "C"
+
+/* The layout of the reference's per-ray debug print (traceRay with dbp = true, src/raytrace.zig:133-146, 149-154,
+ * 164-198). */
+extern "C" int vr_print_ray_trace(const vr_ray_report *r, const vr_ray_step *steps, const char *path)
+{
+    if (!r || (r->n_stored && !steps)) return VR_EARG;
+    FILE *f = path ? std::fopen(path, "w") : stderr;
+    if (!f) return VR_EIO;
+    const float t = r->t_entry;
+    std::fprintf(f, " \n\n ### NEW RAY ### \nd= (%.2f %.2f %.2f)  o= (%.2f %.2f %.2f)\nskip to (%.2f %.2f %.2f) t=%.3f\n",
+                 r->dir[0], r->dir[1], r->dir[2], r->origin[0], r->origin[1], r->origin[2], r->origin[0] + r->dir[0] * t,
+                 r->origin[1] + r->dir[1] * t, r->origin[2] + r->dir[2] * t, t);
+    if (r->flag == VR_FLAG_OOB) std::fprintf(f, "\n oob\n \n");
+    static const char *const what[3] = { "ZOOM!", "HIT!", "MOVE!" };
+    for (uint32_t i = 0; i < r->n_stored; i++) {
+        const vr_ray_step &s = steps[i];
+        std::fprintf(f, " \nt=%.3f  r=(%.2f %.2f %.2f)\nnode=%u   size=%u   iso=[%u-%u] v %u\n  res: %s\n", s.t, s.p[0], s.p[1], s.p[2],
+                     s.node, s.size, (unsigned)s.min, (unsigned)s.max, (unsigned)s.isoval, what[s.action < 3 ? s.action : 2]);
+    }
+    if (r->n_stored < r->n_steps) std::fprintf(f, "... %u more iterations not stored\n", r->n_steps - r->n_stored);
+    if (path) std::fclose(f);
+    return VR_OK;
+}

@@ -47,7 +47,54 @@ __global__ __launch_bounds__(256) void vr_k_refine(VrViewK v, const uint8_t *__r
     density[at] = d;
 }
 
+/* ---- one ray, step by step: the reference's debug print as records (src/raytrace.zig:133-198) ---- */
+struct RawFetch {
+    const uint32_t *nodes;
+    __device__ uint32_t operator()(uint32_t idx) const { return nodes[idx]; }
+};
+struct StepStore {
+    vr_ray_step *out;
+    uint32_t cap, n, iso;
+    __device__ void step(float t, float px, float py, float pz, uint32_t node, uint32_t size, uint32_t word, uint32_t action)
+    {
+        if (n < cap) {
+            vr_ray_step s;
+            s.t = t; s.p[0] = px; s.p[1] = py; s.p[2] = pz;
+            s.node = node; s.size = size;
+            s.min = (uint8_t)(word & 0xffu); s.max = (uint8_t)((word >> 8) & 0xffu);
+            s.isoval = (uint8_t)iso; s.action = (uint8_t)action;
+            out[n] = s;
+        }
+        n++;
+    }
+};
+
+__global__ void vr_k_trace_ray(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t iso, uint32_t xi, uint32_t yi,
+                               vr_ray_step *__restrict__ steps, uint32_t cap, vr_ray_report *__restrict__ report)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const VrRay ray = vr_make_ray(v, xi, yi);
+    StepStore store{ steps, cap, 0u, iso };
+    const VrHit h = vr_trace_restart(v, ray, iso, RawFetch{ nodes }, store);
+    vr_ray_report r;
+    r.origin[0] = v.ox; r.origin[1] = v.oy; r.origin[2] = v.oz;
+    r.dir[0] = ray.dx; r.dir[1] = ray.dy; r.dir[2] = ray.dz;
+    r.t_entry = ray.t;
+    r.t_final = h.flag == VR_FLAG_OOB ? 0.0f : h.t;
+    r.flag = h.flag;
+    r.n_steps = store.n;
+    r.n_stored = store.n < cap ? store.n : cap;
+    *report = r;
+}
+
 } // namespace
+
+hipError_t vr_launch_trace_ray(hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_raw, uint32_t iso, uint32_t xi,
+                               uint32_t yi, vr_ray_step *d_steps, uint32_t cap, vr_ray_report *d_report)
+{
+    hipLaunchKernelGGL(vr_k_trace_ray, dim3(1), dim3(64), 0, stream, view, d_nodes_raw, iso, xi, yi, d_steps, cap, d_report);
+    return hipGetLastError();
+}
 
 hipError_t vr_launch_trilerp(hipStream_t stream, const float *d_in, uint64_t n, float *d_out)
 {

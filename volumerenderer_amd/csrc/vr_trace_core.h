@@ -174,8 +174,17 @@ VR_HD uint8_t vr_shade(float t)
  * iteration, every MOVE goes back to heap index 0.  This is the anchor the faster variant is
  * checked against on the GPU.
  * ---------------------------------------------------------------------------------------- */
-template <class NodeFetch>
-VR_HD VrHit vr_trace_restart(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch)
+/* Hook of the literal loop: step() sees every iteration the way the reference's debug print does
+ * (src/raytrace.zig:164-198): t, the point, the node and its box size, its density range, and what happens next. */
+#define VR_STEP_ZOOM 0u
+#define VR_STEP_HIT 1u
+#define VR_STEP_MOVE 2u
+struct VrNoSteps {
+    VR_HD void step(float, float, float, float, uint32_t, uint32_t, uint32_t, uint32_t) {}
+};
+
+template <class NodeFetch, class Steps>
+VR_HD VrHit vr_trace_restart(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Steps &steps)
 {
     VrHit h;
     h.t = 0.0f; h.flag = 2u; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
@@ -193,8 +202,11 @@ VR_HD VrHit vr_trace_restart(const VrViewK &v, const VrRay &ray, uint32_t iso, N
         if (idx >= v.n_slots || depth > VR_MAX_DEPTH) { h.error = 1; break; }
         uint32_t n = fetch(idx);
         uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
+        const uint32_t size = (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]);
+        steps.step(t, px, py, pz, idx, size, n,
+                   mn <= iso && iso <= mx ? (size == 1u ? VR_STEP_HIT : VR_STEP_ZOOM) : VR_STEP_MOVE);
         if (mn <= iso && iso <= mx) {
-            if ((hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]) == 1u) {
+            if (size == 1u) {
                 h.t = t; h.flag = 1u; h.node = idx;
                 h.cell = cell[0] | (cell[1] << 8) | (cell[2] << 16);
                 return h;
@@ -235,6 +247,13 @@ VR_HD VrHit vr_trace_restart(const VrViewK &v, const VrRay &ray, uint32_t iso, N
     h.t = t;
     h.flag = 0u;
     return h;
+}
+
+template <class NodeFetch>
+VR_HD VrHit vr_trace_restart(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch)
+{
+    VrNoSteps none;
+    return vr_trace_restart(v, ray, iso, fetch, none);
 }
 
 /* ------------------------------------------------------------------------------------------
