@@ -115,6 +115,52 @@ def test_wide_sweep_and_row_shards(oracle):
         assert total == sum(s["nodes_checked"] for s in out["stats"])
 
 
+def test_wide_sweep_kernel_every_iso_value_matches_wide_oracle(oracle):
+    """The sweep kernel with the wide lane code (one traversal for every iso value that cannot change a range test on
+    its way): all 256 iso values of volumes with coordinates beyond 255 against one oracle render each -- pixels,
+    cell, t bits, hit leaf, reference-defined check count, all 7 counters -- and, at a size where waves run full, the
+    frames and counters of the one-traversal-per-iso kernel."""
+    import torch
+    rng = np.random.default_rng(8)
+    for shape, kind, W, H in [((300, 24, 20), "noise", 72, 56), ((40, 520, 36), "smooth", 96, 64), ((33, 20, 700), "sparse", 64, 48)]:
+        vox = random_volume(rng, shape, kind)
+        nodes, rd, _ = oracle.build_kdt(vox, wide=True)
+        pos, forw, up = oracle.main_camera(vox.shape)
+        with vr.Renderer(0) as r:
+            r.upload_kdt(vr.SlimKDT(nodes, rd, wide=True))
+            r.set_kernel(capi.KERNEL_SWEEP)
+            out = r.renderSweep(pos, forw, up, W, H, 2.5, 0, 256, taps=True)
+        hits = 0
+        for j in range(0, 256, 2):
+            ref = oracle.render(nodes, rd, pos, forw, up, W, H, 2.5, j, wide=True)
+            got = {k: out[k][j] for k in ("rgb", "cell_flag", "t", "checked", "node")}
+            assert_same_render(got, ref, "wide sweep kernel %s iso %d" % (shape, j))
+            st, o = out["stats"][j], ref["stats"]
+            assert (st["nodes_checked"], st["hit_count"], st["miss_count"], st["oob_count"], st["escape_help_events"], st["moves"],
+                    st["errors"]) == (o.nodes_checked, o.hit_count, o.miss_count, o.oob_count, o.escape_help_events, o.moves, 0)
+            hits += o.hit_count
+        assert hits > 1000
+    vox = datasets.gyroid_noise(320)
+    pos, forw, up = oracle.main_camera(vox.shape)
+    L = capi.lib()
+    W = H = 768
+    v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+    with vr.Renderer(0) as r:
+        r.upload_volume(vr.Data(vox))
+        r.build_kdt("AlwaysCenter")
+        res = []
+        for variant in (capi.KERNEL_PIPELINE, capi.KERNEL_SWEEP):
+            r.set_kernel(variant)
+            d_rgb = torch.empty((64, H, W, 3), dtype=torch.uint8, device="cuda")
+            d_stats = torch.zeros((64, 7), dtype=torch.int64, device="cuda")
+            capi.check(L.vr_render_device(r.handle, C.byref(v), 100, 64, 0, H, d_rgb.data_ptr(), d_stats.data_ptr(), None, None),
+                       "vr_render_device")
+            capi.check(L.vr_sync(r.handle), "vr_sync")
+            res.append((d_rgb, d_stats.cpu().numpy()))
+    assert (res[0][1] == res[1][1]).all() and int(res[0][1][:, 1].sum()) > 10 ** 6 and int(res[0][1][:, 6].sum()) == 0
+    assert bool(torch.equal(res[0][0], res[1][0]))
+
+
 def test_wide_malformed_tree_is_refused_at_upload():
     rng = np.random.default_rng(5)
     nodes = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)

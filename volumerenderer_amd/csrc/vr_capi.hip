@@ -435,7 +435,7 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
                                 row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1));
     if (timing) c->ev_used += 2;
-    if (!fixed_scratch && !c->wide && (variant == VR_KERNEL_SWEEP || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u)))
+    if (!fixed_scratch && (variant == VR_KERNEL_SWEEP || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u)))
         c->info_off = vr_pipeline_info_offset(view->width, row_end - row_begin);
     return VR_OK;
 }

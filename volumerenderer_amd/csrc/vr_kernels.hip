@@ -726,7 +726,79 @@ __host__ __device__ __forceinline__ uint32_t sweep_stat_words(uint32_t iso_count
     return words + (words & 1u);
 }
 
-template <bool TAPS>
+/* ---- the sweep kernel's lane code for the two tree formats ---- */
+struct WideFetch {
+    const uint32_t *nodes;
+    __device__ __forceinline__ uint32_t operator()(uint32_t idx) const { return nodes[idx]; }
+};
+
+template <uint32_t STRIDE>
+struct LdsPath {
+    uint32_t *col; /* this thread's column of the [VR_WIDE_MAX_DEPTH][STRIDE] path store */
+    __device__ __forceinline__ uint32_t get(uint32_t d) const { return col[d * STRIDE]; }
+    __device__ __forceinline__ void set(uint32_t d, uint32_t w) { col[d * STRIDE] = w; }
+};
+
+
+__device__ __forceinline__ float lane_f(float x, uint32_t src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src)); }
+
+/* trees within the reference's range: flattened array, top levels in LDS, path stack of bound words */
+struct SweepNarrow {
+    typedef VrLane Lane;
+    typedef LdsStack<kTraceThreads> Store;
+    typedef TopFetch Fetch;
+    static constexpr uint32_t kFlagShift = 24u;
+    __device__ static __forceinline__ Store store(uint32_t *) { return Store(); }
+    __device__ static __forceinline__ Fetch fetch(const uint32_t *nodes, const uint32_t *s_top, uint32_t n_top) { return TopFetch(nodes, s_top, n_top); }
+    __device__ static __forceinline__ void begin(Lane &L, Store &st, const VrViewK &v, float dx, float dy, float dz, float t) { vr_lane_begin(L, st, v, dx, dy, dz, t); }
+    __device__ static __forceinline__ uint32_t cell(const Lane &L) { return L.cell; }
+    __device__ static __forceinline__ void restart(Lane &L, Store &st, const VrViewK &v, float t0, uint32_t c0) { vr_lane_restart(L, st, v, t0, c0); }
+    __device__ static __forceinline__ uint32_t descend(Lane &L, const VrViewK &, uint32_t iso, const Fetch &f, Store &st, VrIsoUpper &track)
+    {
+        return vr_lane_descend(L, iso, f, st, kSweepDescendTrips, track);
+    }
+    __device__ static __forceinline__ bool move(Lane &L, const VrViewK &v, uint32_t &esc) { return vr_lane_move(L, v, esc); }
+    __device__ static __forceinline__ bool pop(Lane &L, Store &st) { return vr_lane_pop(L, st, kSweepPopTrips); }
+    __device__ static __forceinline__ uint32_t cell_tap(const Lane &L) { return vr_unpack_cell(L.cell); }
+    __device__ static __forceinline__ uint32_t node_tap(const Lane &L) { return L.g - 1u; }
+    /* the victim's ray, read by every lane, kept by the thief */
+    __device__ static __forceinline__ void adopt(Lane &L, uint32_t victim, bool thief)
+    {
+        const float dx = lane_f(L.dx, victim), dy = lane_f(L.dy, victim), dz = lane_f(L.dz, victim);
+        const float rx = lane_f(L.rx, victim), ry = lane_f(L.ry, victim), rz = lane_f(L.rz, victim);
+        const uint32_t pm = (uint32_t)__builtin_amdgcn_readlane((int)L.posmask, victim);
+        if (thief) { L.dx = dx; L.dy = dy; L.dz = dz; L.rx = rx; L.ry = ry; L.rz = rz; L.posmask = pm; }
+    }
+};
+
+/* volumes beyond 256 voxels per axis: the wide node array as it is, one path word per level in LDS */
+struct SweepWide {
+    typedef VrWideLane Lane;
+    typedef LdsPath<kTraceThreads> Store;
+    typedef WideFetch Fetch;
+    static constexpr uint32_t kFlagShift = VR_WIDE_FLAG_SHIFT;
+    __device__ static __forceinline__ Store store(uint32_t *s_dyn) { return Store{ s_dyn + threadIdx.x }; }
+    __device__ static __forceinline__ Fetch fetch(const uint32_t *nodes, const uint32_t *, uint32_t) { return WideFetch{ nodes }; }
+    __device__ static __forceinline__ void begin(Lane &L, Store &, const VrViewK &v, float dx, float dy, float dz, float t) { vr_wide_begin(L, v, dx, dy, dz, t); }
+    __device__ static __forceinline__ uint32_t cell(const Lane &L) { return L.c; }
+    __device__ static __forceinline__ void restart(Lane &L, Store &, const VrViewK &v, float t0, uint32_t c0) { vr_wide_restart(L, v, t0, c0); }
+    __device__ static __forceinline__ uint32_t descend(Lane &L, const VrViewK &v, uint32_t iso, const Fetch &f, Store &st, VrIsoUpper &track)
+    {
+        return vr_wide_descend(L, v, iso, f, st, kSweepDescendTrips, track);
+    }
+    __device__ static __forceinline__ bool move(Lane &L, const VrViewK &v, uint32_t &esc) { return vr_wide_move(L, v, esc); }
+    __device__ static __forceinline__ bool pop(Lane &L, Store &st) { return vr_wide_pop(L, st, kSweepPopTrips); }
+    __device__ static __forceinline__ uint32_t cell_tap(const Lane &L) { return L.c; }
+    __device__ static __forceinline__ uint32_t node_tap(const Lane &L) { return L.idx; }
+    __device__ static __forceinline__ void adopt(Lane &L, uint32_t victim, bool thief)
+    {
+        const float dx = lane_f(L.dx, victim), dy = lane_f(L.dy, victim), dz = lane_f(L.dz, victim);
+        const float rx = lane_f(L.rx, victim), ry = lane_f(L.ry, victim), rz = lane_f(L.rz, victim);
+        if (thief) { L.dx = dx; L.dy = dy; L.dz = dz; L.rx = rx; L.ry = ry; L.rz = rz; }
+    }
+};
+
+template <bool TAPS, class OPS>
 __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top,
                                                             uint32_t stack_rows,
                                                             const float4 *__restrict__ ray_dt,
@@ -746,8 +818,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     for (uint32_t i = threadIdx.x; i < sweep_stat_words(iso_count); i += kTraceThreads) s_dyn[stack_rows * kTraceThreads + i] = 0u;
     for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_top[i] = nodes[i];
     __syncthreads();
-    LdsStack<kTraceThreads> stack;
-    const TopFetch fetch(nodes, s_top, n_top);
+    typename OPS::Store stack = OPS::store(s_dyn);
+    const typename OPS::Fetch fetch = OPS::fetch(nodes, s_top, n_top);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_active = *n_active_ptr;
@@ -774,7 +846,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     const unsigned long long tick_begin = __builtin_amdgcn_s_memrealtime();
     unsigned long long tick_empty = 0;
     uint32_t n_walks = 0;
-    VrLane L;
+    typename OPS::Lane L;
     WaveChunk chunk;
     VrIsoUpper track;
     track.upper = 255u;
@@ -794,9 +866,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 const uint32_t blk = in >> 6, ray = grp * 64u + (in & 63u);
                 const float4 r = ray_dt[ray < n_active ? ray : 0u];
                 pix = ray_pix[ray < n_active ? ray : 0u];
-                vr_lane_begin(L, stack, v, r.x, r.y, r.z, r.w);
+                OPS::begin(L, stack, v, r.x, r.y, r.z, r.w);
                 t0 = r.w;
-                cell0 = L.cell;
+                cell0 = OPS::cell(L);
                 iso = iso_begin + blk * block_isos;
                 iso_last = iso_begin + (blk * block_isos + block_isos < iso_count ? blk * block_isos + block_isos : iso_count) - 1u;
                 track.upper = 255u;
@@ -822,15 +894,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 if ((best >> 6) < kSweepStealMin) break;
                 const uint32_t victim = __builtin_amdgcn_readfirstlane(best & 63u);
                 const uint32_t thief = (uint32_t)__ffsll((long long)idle_now) - 1u;
-                /* the victim's ray, read by every lane, kept by the thief */
-                const float s_dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.dx), victim));
-                const float s_dy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.dy), victim));
-                const float s_dz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.dz), victim));
-                const float s_rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.rx), victim));
-                const float s_ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.ry), victim));
-                const float s_rz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.rz), victim));
-                const float s_t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t0), victim));
-                const uint32_t s_pm = (uint32_t)__builtin_amdgcn_readlane((int)L.posmask, victim);
+                const float s_t0 = lane_f(t0, victim);
                 const uint32_t s_c0 = (uint32_t)__builtin_amdgcn_readlane((int)cell0, victim);
                 const uint32_t s_px = (uint32_t)__builtin_amdgcn_readlane((int)pix, victim);
                 const uint32_t s_iso = (uint32_t)__builtin_amdgcn_readlane((int)iso, victim);
@@ -840,11 +904,11 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 d_acc[9] += 1;
 #endif
                 if (lane == victim) iso_last = mid;
+                OPS::adopt(L, victim, lane == thief);
                 if (lane == thief) {
-                    L.dx = s_dx; L.dy = s_dy; L.dz = s_dz; L.rx = s_rx; L.ry = s_ry; L.rz = s_rz; L.posmask = s_pm;
                     t0 = s_t0; cell0 = s_c0; pix = s_px;
                     iso = mid + 1u; iso_last = s_last;
-                    vr_lane_restart(L, stack, v, t0, cell0);
+                    OPS::restart(L, stack, v, t0, cell0);
                     track.upper = 255u;
                     moves = 0; esc = 0;
                     alive = true;
@@ -860,19 +924,19 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
         if (alive) {
             uint32_t go = VR_GO_MORE;
             /* ---- descend while the node's density range holds the iso value (bounded) ---- */
-            if (!popping) go = vr_lane_descend(L, iso, fetch, stack, kSweepDescendTrips, track);
+            if (!popping) go = OPS::descend(L, v, iso, fetch, stack, track);
             bool done = false, hit = false;
             uint32_t err = 0;
             if (go == VR_GO_HIT) {
                 done = true; hit = true;
             } else if (go == VR_GO_EXCLUDED) {
                 moves++;
-                bool in_root = vr_lane_move(L, v, esc);
+                bool in_root = OPS::move(L, v, esc);
                 if (L.checked > VR_MAX_CHECKED) { in_root = false; err = 1; }
                 if (in_root) popping = true; else done = true; /* left the volume: a miss (src/raytrace.zig:66-68) */
             }
             /* ---- pop to the lowest ancestor that holds the new point (bounded) ---- */
-            if (popping && !done) popping = !vr_lane_pop(L, stack, kSweepPopTrips);
+            if (popping && !done) popping = !OPS::pop(L, stack);
 
             if (done) {
                 n_walks++;
@@ -895,8 +959,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                     for (uint32_t k = k0; k < k1; k++, p += frame_bytes) { p[0] = g; p[1] = g; p[2] = g; }
                 }
                 if (TAPS) {
-                    const uint32_t cf = hit ? (vr_unpack_cell(L.cell) | (VR_FLAG_HIT << 24)) : (VR_FLAG_MISS << 24);
-                    const uint32_t nd = hit ? L.g - 1u : 0u;
+                    const uint32_t cf = hit ? (OPS::cell_tap(L) | (VR_FLAG_HIT << OPS::kFlagShift)) : (VR_FLAG_MISS << OPS::kFlagShift);
+                    const uint32_t nd = hit ? OPS::node_tap(L) : 0u;
                     for (uint32_t k = k0; k < k1; k++) {
                         const uint64_t at = (uint64_t)k * frame_pixels + pix;
                         if (taps.cell_flag) taps.cell_flag[at] = cf;
@@ -909,7 +973,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 if (iso > iso_last) {
                     alive = false;
                 } else { /* same ray, next open iso value */
-                    vr_lane_restart(L, stack, v, t0, cell0);
+                    OPS::restart(L, stack, v, t0, cell0);
                     track.upper = 255u;
                     moves = 0; esc = 0;
                     popping = false;
@@ -982,18 +1046,6 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
  * src/typedef.zig:1): the kernels below walk the wide node array as built, or as uploaded and validated (lane
  * code in vr_trace_wide.h), with the lane's path -- one word per level -- in LDS as [level][thread] words.  A wide tree
  * is up to 2^31 four-byte words (8 GiB); node fetches use 64-bit addresses. */
-struct WideFetch {
-    const uint32_t *nodes;
-    __device__ __forceinline__ uint32_t operator()(uint32_t idx) const { return nodes[idx]; }
-};
-
-template <uint32_t STRIDE>
-struct LdsPath {
-    uint32_t *col; /* this thread's column of the [VR_WIDE_MAX_DEPTH][STRIDE] path store */
-    __device__ __forceinline__ uint32_t get(uint32_t d) const { return col[d * STRIDE]; }
-    __device__ __forceinline__ void set(uint32_t d, uint32_t w) { col[d * STRIDE] = w; }
-};
-
 /* one thread per pixel and iso value: a 16 x 16 pixel block, each wave an 8 x 8 tile */
 __global__ __launch_bounds__(256) void vr_k_render_wide(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t iso_begin,
                                                         uint32_t row_begin, uint32_t n_rows, uint8_t *__restrict__ rgb,
@@ -1261,7 +1313,8 @@ hipError_t vr_device_setup(int device)
     if (g_setup_done[device]) return hipSuccess;
     hipError_t e;
     const void *fns[] = { (const void *)vr_k_trace<false>,      (const void *)vr_k_trace<true>,
-                          (const void *)vr_k_sweep<false>,      (const void *)vr_k_sweep<true>,
+                          (const void *)vr_k_sweep<false, SweepNarrow>, (const void *)vr_k_sweep<true, SweepNarrow>,
+                          (const void *)vr_k_sweep<false, SweepWide>,   (const void *)vr_k_sweep<true, SweepWide>,
                           (const void *)vr_k_trace_wide<false>, (const void *)vr_k_trace_wide<true> };
     for (const void *fn : fns)
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u))) != hipSuccess) return e;
@@ -1392,7 +1445,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                            (void *)&d_rgb, (void *)&d_stats, (void *)&slots, (void *)&taps };
     void **args = sweep ? args_sweep : args_trace;
-    const void *fn = sweep ? (any_tap ? (const void *)vr_k_sweep<true> : (const void *)vr_k_sweep<false>)
+    const void *fn = sweep ? (any_tap ? (const void *)vr_k_sweep<true, SweepNarrow> : (const void *)vr_k_sweep<false, SweepNarrow>)
                            : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
 
     if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
@@ -1470,11 +1523,28 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         if (ev_end) e = hipEventRecord(ev_end, stream);
         return e;
     }
+    /* a block of iso values: the sweep kernel with the wide lane code (traversals shared between iso values) */
+    const bool sweep = variant == VR_KERNEL_SWEEP || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u);
     Prepass pp;
-    if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, 0u, d_rgb, d_stats, taps,
+    if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
                             VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp)) != hipSuccess)
         return e;
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
+    if (sweep) {
+        const uint32_t n_top = 0u, stack_rows = VR_WIDE_MAX_DEPTH;
+        const size_t lds = ((size_t)stack_rows * kTraceThreads + sweep_stat_words(iso_count)) * sizeof(uint32_t);
+        const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
+        const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
+        const void *fn = any_tap ? (const void *)vr_k_sweep<true, SweepWide> : (const void *)vr_k_sweep<false, SweepWide>;
+        void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&stack_rows, (void *)&pp.ray_dt, (void *)&pp.ray_pix,
+                         (void *)&pp.n_active, (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
+                         (void *)&d_rgb, (void *)&d_stats, (void *)&taps };
+        if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
+        if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, lds, stream)) != hipSuccess) return e;
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (ev_end) e = hipEventRecord(ev_end, stream);
+        return e;
+    }
     const void *fn = any_tap ? (const void *)vr_k_trace_wide<true> : (const void *)vr_k_trace_wide<false>;
     const size_t lds = (size_t)VR_WIDE_MAX_DEPTH * kWideThreads * sizeof(uint32_t);
     const uint32_t blocks = (uint32_t)n_cus * kWideBlocksPerCu;

@@ -87,21 +87,39 @@ VR_HD uint32_t vr_wide_split(VrWideLane &L, uint32_t part, uint32_t axis, uint32
 /* SpaceTracker.zoom (src/SlimKDT.zig:90-103) for at most max_trips levels: until a node excludes the iso value
  * (VR_GO_EXCLUDED, MOVE next), a leaf holds it (VR_GO_HIT, src/raytrace.zig:178-187) or the budget is used up
  * (VR_GO_MORE) */
-template <class NodeFetch, class Path>
+template <class NodeFetch, class Path, class Track>
 VR_HD uint32_t vr_wide_descend(VrWideLane &L, const VrViewK &v, uint32_t iso, const NodeFetch &fetch, Path &path,
-                               uint32_t max_trips)
+                               uint32_t max_trips, Track &track)
 {
     for (uint32_t trip = 0; trip < max_trips; trip++) {
         const uint32_t n = fetch(L.idx);
         L.checked++;
         const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
-        if (!(mn <= iso && iso <= mx)) return VR_GO_EXCLUDED;
+        if (!(mn <= iso && iso <= mx)) { track.excluded(n, iso); return VR_GO_EXCLUDED; }
+        track.passed(n); /* the density range sits in bits 0-15 of both node words */
         if (L.hi - L.lo == VR_F_ONES) return VR_GO_HIT;
         const uint32_t axis = VR_WIDE_AXIS(n), part = VR_WIDE_PART(n);
         path.set(L.d, vr_wide_split(L, part, axis, axis * 10u));
         L.d++;
     }
     return VR_GO_MORE;
+}
+
+template <class NodeFetch, class Path>
+VR_HD uint32_t vr_wide_descend(VrWideLane &L, const VrViewK &v, uint32_t iso, const NodeFetch &fetch, Path &path,
+                               uint32_t max_trips)
+{
+    VrNoIsoTrack none;
+    return vr_wide_descend(L, v, iso, fetch, path, max_trips, none);
+}
+
+/* Puts a lane back at the entry point of its ray (for the next iso value of a sweep). */
+VR_HD void vr_wide_restart(VrWideLane &L, const VrViewK &v, float t_entry, uint32_t cell_entry)
+{
+    L.t = t_entry;
+    L.c = cell_entry;
+    L.lo = 0; L.hi = vr_pack10(v.rdx, v.rdy, v.rdz);
+    L.idx = 0; L.d = 0; L.checked = 0;
 }
 
 /* MOVE (src/raytrace.zig:199-246) out of the box of the excluded node.  Returns false when the point has left
