@@ -269,6 +269,15 @@ int vr_render_device_noalloc(vr_ctx *ctx, const vr_view *view, uint32_t iso_begi
                              uint32_t row_begin, uint32_t row_end, void *d_rgb24, void *d_stats,
                              const vr_taps *d_taps, void *stream);
 
+/* Self-test of the device: the traversal kernels use three GPU-only fast paths -- floor through one conversion
+ * instruction, 2g + bit through the carry of the lane mask, and the exit-plane division of the MOVE
+ * (src/geo.zig:406-426) by a per-ray reciprocal with FMA corrections -- whose portable definitions are what the CPU
+ * emulation of the lane code runs.  This evaluates each on n_samples pseudo-random operands on the GPU next to its
+ * portable definition (the division next to the correctly rounded hardware divide) and counts the results that
+ * differ, one count per fast path (floor, carry, division): all 0 on a healthy device.  No counterpart in the
+ * reference. */
+int vr_selftest(vr_ctx *ctx, uint64_t n_samples, uint64_t mismatches_out[3]);
+
 /* ---- trilinear refinement ---------------------------------------------------------------- */
 
 /* raytrace.trilerp (src/raytrace.zig:257-291) on the GPU, bit for bit (strict f32, the reference's operation

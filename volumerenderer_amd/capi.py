@@ -39,7 +39,7 @@ HEURISTICS = {
 EXPORTS = [
     "vr_strerror", "vr_load_ucd", "vr_save_ucd", "vr_save_kdt", "vr_load_kdt", "vr_host_build_kdt", "vr_host_prepare_kdt", "vr_host_check_kdt_wide", "vr_prepared_words", "vr_main_camera", "vr_free", "vr_alloc_host", "vr_free_host", "vr_write_png_rgb24", "vr_write_ppm_rgb24", "vr_ctx_create",
     "vr_ctx_destroy", "vr_upload_volume", "vr_upload_kdt", "vr_build_kdt", "vr_download_kdt", "vr_upload_kdt_wide", "vr_download_kdt_wide", "vr_render",
-    "vr_render_sweep", "vr_render_device", "vr_render_device_noalloc", "vr_render_device_bands", "vr_mgpu_render_sweep", "vr_trace_ray", "vr_print_ray_trace", "vr_trilerp_device", "vr_refine_device", "vr_sync", "vr_sweep_info_read", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
+    "vr_render_sweep", "vr_render_device", "vr_render_device_noalloc", "vr_render_device_bands", "vr_mgpu_render_sweep", "vr_selftest", "vr_trace_ray", "vr_print_ray_trace", "vr_trilerp_device", "vr_refine_device", "vr_sync", "vr_sweep_info_read", "vr_set_timing", "vr_timing_read", "vr_set_kernel",
     "vr_kernel_name",
 ]
 
@@ -142,6 +142,7 @@ def lib():
                                          C.c_uint32, vp, vp, C.POINTER(Taps), vp]
     L.vr_mgpu_render_sweep.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(View), C.c_uint32, C.c_uint32, C.c_int, vp,
                                        C.POINTER(RenderStats)]
+    L.vr_selftest.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.vr_trace_ray.argtypes = [vp, C.POINTER(View), C.c_uint8, C.c_uint32, C.c_uint32, C.POINTER(RayStep), C.c_uint32,
                                C.POINTER(RayReport)]
     L.vr_print_ray_trace.argtypes = [C.POINTER(RayReport), C.POINTER(RayStep), C.c_char_p]

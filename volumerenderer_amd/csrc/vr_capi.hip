@@ -667,6 +667,22 @@ int vr_trace_ray(vr_ctx *c, const vr_view *view, uint8_t isoval, uint32_t xi, ui
     return e == hipSuccess ? VR_OK : VR_EHIP_BASE - (int)e;
 }
 
+int vr_selftest(vr_ctx *c, uint64_t n_samples, uint64_t *mismatches_out)
+{
+    if (!c || !mismatches_out || !n_samples) return VR_EARG;
+    VR_HIP(hipSetDevice(c->device));
+    unsigned long long *d_bad = nullptr, bad[3] = { 0, 0, 0 }; /* floor, carry, division */
+    hipError_t e = hipMalloc((void **)&d_bad, sizeof bad);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof bad, c->stream);
+    if (e == hipSuccess) e = vr_launch_selftest(c->stream, n_samples, d_bad);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
+    if (d_bad) (void)hipFree(d_bad);
+    if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
+    for (int i = 0; i < 3; i++) mismatches_out[i] = bad[i];
+    return VR_OK;
+}
+
 int vr_trilerp_device(vr_ctx *c, const float *d_in, uint64_t n, float *d_out, void *stream)
 {
     if (!c || (n && (!d_in || !d_out))) return VR_EARG;

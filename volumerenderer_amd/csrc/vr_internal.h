@@ -82,6 +82,9 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
 hipError_t vr_launch_trace_ray(hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_raw, uint32_t iso, uint32_t xi,
                                uint32_t yi, vr_ray_step *d_steps, uint32_t cap, vr_ray_report *d_report);
 
+/* n samples each of the lane code's GPU-only fast paths against their portable definitions; *d_bad += mismatches */
+hipError_t vr_launch_selftest(hipStream_t stream, uint64_t n, unsigned long long *d_bad);
+
 /* Trilinear refinement (vr_refine.hip): trilerp on n packed argument records, and the post-pass over the hit taps. */
 hipError_t vr_launch_trilerp(hipStream_t stream, const float *d_in, uint64_t n, float *d_out);
 hipError_t vr_launch_refine(hipStream_t stream, const VrViewK &view, bool wide, const uint8_t *d_vox, uint32_t ry, uint32_t rz,

@@ -87,7 +87,49 @@ __global__ void vr_k_trace_ray(VrViewK v, const uint32_t *__restrict__ nodes, ui
     *report = r;
 }
 
+/* ---- self-test of the lane code's GPU-only fast paths against their portable definitions ---- */
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void vr_k_selftest(uint64_t n, unsigned long long *__restrict__ bad)
+{
+    uint32_t wrong = 0, w_floor = 0, w_carry = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const uint32_t a = mix32((uint32_t)i * 2u + 1u), b = mix32((uint32_t)i * 2u + 2u) ^ (uint32_t)(i >> 31);
+        /* floor to a saturating i32: every bit pattern, NaN and infinities included */
+        const float x = __builtin_bit_cast(float, a);
+        int32_t want;
+        if (x != x) want = (a >> 31) ? INT32_MIN : INT32_MAX; /* a NaN saturates by its sign: outside every box */
+        else if (x >= 2147483648.0f) want = INT32_MAX;
+        else if (x < -2147483648.0f) want = INT32_MIN;
+        else want = (int32_t)floorf(x);
+        w_floor += vr_floor_i32(x) != want;
+        /* 2 g + bit through the carry of the lane mask */
+        const bool bit = (b >> 7) & 1u;
+        w_carry += vr_twice_plus(a >> 1, bit) != 2u * (a >> 1) + (bit ? 1u : 0u);
+        /* the reciprocal division of the MOVE against the correctly rounded divide, on operands of the shape the path
+         * produces: numerator = plane offset (0..1023) minus an origin coordinate, denominator = a direction component */
+        const float off = (float)(b & 1023u), o = ((float)(int32_t)(a >> 8) - 8388608.0f) * (1.0f / 16384.0f);
+        float d = ((float)(b >> 9) + 0.5f) * (1.0f / 8388608.0f) * ((a & 1u) ? 1.0f : -1.0f);
+        if (fabsf(d) < 1e-8f) d = 1e-8f;
+        const float num = off - o, q = num / d, r = 1.0f / d;
+        wrong += __builtin_bit_cast(uint32_t, vr_div(num, d, r)) != __builtin_bit_cast(uint32_t, q);
+    }
+    if (w_floor) atomicAdd(bad, (unsigned long long)w_floor);
+    if (w_carry) atomicAdd(bad + 1, (unsigned long long)w_carry);
+    if (wrong) atomicAdd(bad + 2, (unsigned long long)wrong);
+}
+
 } // namespace
+
+hipError_t vr_launch_selftest(hipStream_t stream, uint64_t n, unsigned long long *d_bad)
+{
+    hipLaunchKernelGGL(vr_k_selftest, dim3(2048), dim3(256), 0, stream, n, d_bad);
+    return hipGetLastError();
+}
 
 hipError_t vr_launch_trace_ray(hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_raw, uint32_t iso, uint32_t xi,
                                uint32_t yi, vr_ray_step *d_steps, uint32_t cap, vr_ray_report *d_report)

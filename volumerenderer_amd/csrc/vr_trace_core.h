@@ -60,7 +60,9 @@ VR_HD uint32_t vr_twice_plus(uint32_t g, bool bit)
 #endif
 }
 
-/* floor(x) as a saturating i32 (NaN -> 0): one conversion instruction on the GPU */
+/* floor(x) as a saturating i32: one conversion instruction on the GPU.  A NaN saturates by its sign bit like an
+ * infinity, so that as an unsigned number it lies outside every box -- Range.containsFloat (src/geo.zig:173-176)
+ * is false for a NaN too. */
 VR_HD int32_t vr_floor_i32(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -68,7 +70,7 @@ VR_HD int32_t vr_floor_i32(float x)
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 #else
-    if (x != x) return 0;
+    if (x != x) return signbit(x) ? INT32_MIN : INT32_MAX;
     if (x >= 2147483648.0f) return INT32_MAX;
     if (x < -2147483648.0f) return INT32_MIN;
     return (int32_t)floorf(x);
