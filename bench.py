@@ -316,6 +316,7 @@ def main():
 
         for _ in range(args.warmup):
             step()
+            torch.cuda.synchronize()  # untimed; lets the library see each warm-up launch's report before the next one
         fence()
         capi.check(L.vr_set_timing(r.handle, 1), "vr_set_timing")
         t0 = time.perf_counter()

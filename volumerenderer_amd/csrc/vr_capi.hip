@@ -48,6 +48,26 @@ struct vr_ctx {
     void *d_tap[4] = { nullptr, nullptr, nullptr, nullptr };
     size_t tap_cap[4] = { 0, 0, 0, 0 };
     size_t info_off = 0; /* where the last sweep-kernel launch in d_work left its report; 0 = none yet */
+    /* The sweep kernel's cut of the iso range, tuned per workload from its own reports.  Every sweep launch in the
+     * context's scratch is tagged with a sequence number and followed by an asynchronous copy of its report into
+     * page-locked memory; a later launch reads whatever report has arrived (it never waits).  For a new workload
+     * (tree, image size, iso range) the default's report decides: a short tail (the queue ran empty late) means fewer,
+     * longer items would save re-walked traversals, a long tail asks for more, anything in between stays.  Up to two
+     * candidates on that side are then tried, each on ONE launch, all other launches using the best cut known; a
+     * candidate stays when its launch was at least 1.5 % shorter.  Results never depend on the cut. */
+    struct SweepTune {
+        uint64_t key = 0;
+        uint32_t seq = 0, seen = 0;
+        uint32_t best_ipl = VR_SWEEP_ITEMS_DEFAULT;
+        uint64_t best_span = 0;
+        uint32_t cand[2] = { 0, 0 };
+        int n_cand = 0, i_cand = 0;
+        int phase = 0;           /* 0 waiting for the default's report, 1 trying candidates, 2 settled */
+        bool cand_launched = false;
+        uint32_t ipl_of_seq[16] = { 0 };
+    } tune;
+    uint64_t tree_id = 0;                 /* changes with every upload / build */
+    unsigned long long *h_info = nullptr; /* page-locked: walks, items, 3 ticks, sequence number */
     /* options */
     int variant = VR_KERNEL_DEFAULT;
     int timing = 0;
@@ -161,6 +181,8 @@ int vr_ctx_create(int device, vr_ctx **out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_info, 64, hipHostMallocDefault);
+    if (e == hipSuccess) std::memset(c->h_info, 0, 64);
     if (e != hipSuccess) {
         vr_ctx_destroy(c);
         return VR_EHIP_BASE - (int)e;
@@ -177,6 +199,7 @@ void vr_ctx_destroy(vr_ctx *c)
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (int i = 0; i < 4; i++)
         if (c->chunk_done[i]) (void)hipEventDestroy(c->chunk_done[i]);
+    if (c->h_info) (void)hipHostFree(c->h_info);
     if (c->d_vox) (void)hipFree(c->d_vox);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     free_prepared(c);
@@ -235,6 +258,7 @@ int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint
     std::free(prepared);
     if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
     c->n_slots = n_slots;
+    c->tree_id++;
     c->max_depth = max_depth;
     c->root_dim[0] = root_dim[0]; c->root_dim[1] = root_dim[1]; c->root_dim[2] = root_dim[2];
     c->wide = false;
@@ -259,6 +283,7 @@ int vr_upload_kdt_wide(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const
     if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes, n_slots * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
     c->n_slots = n_slots;
+    c->tree_id++;
     c->max_depth = max_depth;
     for (int a = 0; a < 3; a++) c->root_dim[a] = root_dim[a];
     c->wide = true;
@@ -286,6 +311,7 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
         c->n_slots = n_slots;
+        c->tree_id++;
         c->max_depth = depth;
         for (int a = 0; a < 3; a++) c->root_dim[a] = c->res[a] - 1u;
         c->wide = true;
@@ -312,6 +338,7 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
         if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
         if (too_deep) return VR_ETOODEEP;
         c->n_slots = (uint64_t)1 << (depth + 1);
+        c->tree_id++;
         c->max_depth = depth;
         for (int a = 0; a < 3; a++) c->root_dim[a] = c->res[a] - 1u;
         c->wide = false;
@@ -330,6 +357,7 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return VR_EHIP_BASE - (int)e;
     c->n_slots = n_slots;
+    c->tree_id++;
     c->max_depth = depth;
     for (int a = 0; a < 3; a++) c->root_dim[a] = c->res[a] - 1u;
     c->wide = false;
@@ -372,6 +400,53 @@ int vr_download_kdt_wide(vr_ctx *c, uint32_t *nodes_out, uint64_t first_slot, ui
         VR_HIP(hipMemcpy(nodes_out, c->d_nodes + first_slot, n_slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return VR_OK;
+}
+
+/* Picks the sweep kernel's items-per-lane for this launch and tags it (see vr_ctx::SweepTune). */
+static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
+                            uint32_t n_rows, uint32_t band_rows, uint32_t *ipl_out, uint32_t *seq_out)
+{
+    static const bool tune_debug = std::getenv("VR_TUNE_DEBUG") != nullptr; /* VR_TUNE_DEBUG=1: the decisions, on stderr */
+    vr_ctx::SweepTune &t = c->tune;
+    uint64_t key = 1469598103934665603ull; /* FNV-1a over what defines the workload's shape (not the camera) */
+    const uint64_t parts[] = { c->tree_id, view->width, view->height, row_begin, n_rows, band_rows, iso_begin, iso_count };
+    for (uint64_t p : parts) { key ^= p; key *= 1099511628211ull; }
+    if (key != t.key) {
+        t = vr_ctx::SweepTune();
+        t.key = key;
+    }
+    /* the newest report that has arrived */
+    const unsigned long long *h = c->h_info;
+    const uint32_t got_seq = (uint32_t)h[5];
+    if (t.phase != 2 && got_seq != 0 && got_seq != t.seen && got_seq <= t.seq && t.seq - got_seq < 16u && h[4] > h[2]) {
+        t.seen = got_seq;
+        const uint32_t ipl = t.ipl_of_seq[got_seq & 15u];
+        const uint64_t span = h[4] - h[2];
+        const double tail = (double)(h[4] - (h[3] < h[4] ? h[3] : h[4])) / (double)span;
+        if (tune_debug)
+            std::fprintf(stderr, "[sweep tune] report of launch %u (now at %u): %u items per lane, span %.3f ms, tail %.3f, phase %d\n", got_seq,
+                         t.seq, ipl, (double)span / 1e5, tail, t.phase);
+        if (t.phase == 0 && ipl == VR_SWEEP_ITEMS_DEFAULT) {
+            t.best_ipl = ipl; t.best_span = span;
+            if (tail < 0.25) { t.cand[0] = 9; t.cand[1] = 6; t.n_cand = 2; }
+            else if (tail > 0.40) { t.cand[0] = 16; t.cand[1] = 20; t.n_cand = 2; }
+            t.phase = t.n_cand ? 1 : 2;
+        } else if (t.phase == 1 && t.cand_launched && ipl == t.cand[t.i_cand]) {
+            const bool better = (double)span < 0.985 * (double)t.best_span;
+            if (better) { t.best_ipl = ipl; t.best_span = span; }
+            t.cand_launched = false;
+            if (better && t.i_cand + 1 < t.n_cand) t.i_cand++;
+            else t.phase = 2;
+        }
+    }
+    uint32_t ipl = t.best_ipl;
+    if (t.phase == 1 && !t.cand_launched) { ipl = t.cand[t.i_cand]; t.cand_launched = true; } /* one launch per candidate */
+    t.seq++;
+    if (t.seq == 0) t.seq = 1;
+    t.ipl_of_seq[t.seq & 15u] = ipl;
+    if (tune_debug) std::fprintf(stderr, "[sweep tune] launch %u: %u items per lane, phase %d\n", t.seq, ipl, t.phase);
+    *ipl_out = ipl;
+    *seq_out = t.seq;
 }
 
 /* Shared body of the two device-resident entry points.  `fixed_scratch` = null: the context's own workspace,
@@ -428,15 +503,21 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         ev0 = c->ev[c->ev_used];
         ev1 = c->ev[c->ev_used + 1];
     }
+    const bool sweep_kernel = variant == VR_KERNEL_SWEEP || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u);
+    uint32_t ipl = VR_SWEEP_ITEMS_DEFAULT, seq = 0;
+    if (sweep_kernel && !fixed_scratch) sweep_tune_next(c, view, iso_begin, iso_count, row_begin, row_end - row_begin, band_rows, &ipl, &seq);
     if (c->wide)
         VR_HIP(vr_launch_render_wide(variant, s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
-                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1));
+                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq));
     else
         VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
-                                row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1));
+                                row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq));
     if (timing) c->ev_used += 2;
-    if (!fixed_scratch && (variant == VR_KERNEL_SWEEP || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u)))
+    if (sweep_kernel && !fixed_scratch) {
         c->info_off = vr_pipeline_info_offset(view->width, row_end - row_begin);
+        if (c->tune.phase != 2) /* the report follows the launch on its stream; the next launch reads it if it has arrived */
+            VR_HIP(hipMemcpyAsync(c->h_info, (const char *)c->d_work + c->info_off, 48, hipMemcpyDeviceToHost, s));
+    }
     return VR_OK;
 }
 

@@ -28,6 +28,11 @@ enum {
     VR_KERNEL_COUNT = 6
 };
 
+/* The sweep kernel cuts the iso range into as many blocks as it takes to have this many (ray, iso block) items per
+ * lane of the grid: more blocks balance better, and every block re-walks its first traversal.  launch_seq tags the
+ * launch in the kernel's report (0 = untagged). */
+#define VR_SWEEP_ITEMS_DEFAULT 12u
+
 /* Device scratch the pipeline variant needs for one call (ray list, tile offsets, queue heads). */
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count);
 
@@ -40,7 +45,8 @@ size_t vr_pipeline_info_offset(uint32_t width, uint32_t n_rows);
 hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_raw,
                             const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
-                            const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end);
+                            const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end,
+                            uint32_t sweep_items_per_lane, uint32_t launch_seq);
 
 /* Once per device, with that device current (vr_ctx_create calls it; safe from several threads): raises the
  * dynamic-LDS ceiling of the persistent kernels, which is a property of the function on the device, and looks
@@ -75,7 +81,7 @@ hipError_t vr_build_span_tree(hipStream_t stream, const uint8_t *d_vox, uint32_t
 hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes,
                                  uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
-                                 hipEvent_t ev_begin, hipEvent_t ev_end);
+                                 hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq);
 
 
 /* One ray with the literal loop, every iteration recorded (vr_refine.hip): d_steps holds cap records, d_report one. */

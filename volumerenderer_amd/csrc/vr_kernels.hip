@@ -315,7 +315,7 @@ __global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, 
         *n_active_out = total;
         /* the sweep kernel's report (vr_sweep_info, 64 bytes behind the ray count): walks, items, first / queue-empty / last tick */
         unsigned long long *info = (unsigned long long *)(n_active_out + 16);
-        info[0] = 0; info[1] = 0; info[2] = ~0ull; info[3] = ~0ull; info[4] = 0;
+        info[0] = 0; info[1] = 0; info[2] = ~0ull; info[3] = ~0ull; info[4] = 0; info[5] = 0;
     }
     /* the small set-up work of a call rides along: empty queues, and the per-iso counters at their starting
      * values (every pixel that never enters the volume is OOB in every frame) */
@@ -692,9 +692,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
  *
  * Per-iso counters go through difference arrays in LDS: +x at the first iso value of an interval, -x
  * behind its last; a prefix sum per block at the end, then one global atomic per iso value and counter. */
-#ifndef VR_SWEEP_ITEMS_PER_LANE
-#define VR_SWEEP_ITEMS_PER_LANE 12
-#endif
+/* (ray, iso block) items per lane of the grid that the iso range is cut for: a launch argument (vr_internal.h:
+ * VR_SWEEP_ITEMS_DEFAULT; the context tunes it per workload from the kernel's own reports) */
 #ifndef VR_SWEEP_DESCEND_TRIPS
 #define VR_SWEEP_DESCEND_TRIPS 5
 #endif
@@ -807,7 +806,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                                                             uint32_t *__restrict__ head, uint32_t iso_begin,
                                                             uint32_t iso_count, uint64_t frame_pixels,
                                                             uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
-                                                            VrTapsK taps)
+                                                            VrTapsK taps, uint32_t items_per_lane, uint32_t launch_seq)
 {
     /* dynamic LDS: [path stacks][check sums: (iso_count + 1) x u64][counters: 5 x (iso_count + 1) x u32][top node words] */
     extern __shared__ uint32_t s_dyn[];
@@ -826,7 +825,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     /* iso blocks: enough (ray, block) items for several per lane of the grid.  Items are numbered group by
      * group of 64 consecutive rays (one tile of the image): the 64 rays on the first iso block, the same rays
      * on the next block, ... */
-    const uint64_t want = (uint64_t)gridDim.x * kTraceThreads * VR_SWEEP_ITEMS_PER_LANE;
+    const uint64_t want = (uint64_t)gridDim.x * kTraceThreads * items_per_lane;
     uint32_t nb = (uint32_t)((want + n_active - 1u) / (n_active ? n_active : 1u));
     nb = nb < 1u ? 1u : (nb > VR_SWEEP_MAX_BLOCKS ? VR_SWEEP_MAX_BLOCKS : nb);
     nb = nb > iso_count ? iso_count : nb;
@@ -1014,7 +1013,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(&info[0], (unsigned long long)s_cnt[kSweepCounters * n_k]);
-        if (blockIdx.x == 0) info[1] = n_items;
+        if (blockIdx.x == 0) { info[1] = n_items; info[5] = launch_seq; }
         atomicMax(&info[4], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
     if (threadIdx.x < kSweepCounters) {
@@ -1372,7 +1371,8 @@ static uint32_t lds_top_levels(uint32_t max_depth, uint64_t n_slots, size_t stat
 hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_raw,
                             const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
-                            const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end)
+                            const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end,
+                            uint32_t sweep_items_per_lane, uint32_t launch_seq)
 {
     const uint32_t n_rows = row_end - row_begin;
     const uint32_t stack_levels = max_depth > 0 ? max_depth : 1u;
@@ -1440,7 +1440,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     WaveStats *slots = !sweep && d_stats && iso_count <= kSlotIsoMax && blocks * (kTraceThreads / 64u) <= kSlotWaveMax ? pp.slots : nullptr;
     void *args_sweep[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
-                           (void *)&d_rgb, (void *)&d_stats, (void *)&taps };
+                           (void *)&d_rgb, (void *)&d_stats, (void *)&taps, (void *)&sweep_items_per_lane, (void *)&launch_seq };
     void *args_trace[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                            (void *)&d_rgb, (void *)&d_stats, (void *)&slots, (void *)&taps };
@@ -1509,7 +1509,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
 hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes,
                                  uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
-                                 hipEvent_t ev_begin, hipEvent_t ev_end)
+                                 hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq)
 {
     const uint32_t n_rows = row_end - row_begin;
     hipError_t e = hipSuccess;
@@ -1538,7 +1538,7 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         const void *fn = any_tap ? (const void *)vr_k_sweep<true, SweepWide> : (const void *)vr_k_sweep<false, SweepWide>;
         void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&stack_rows, (void *)&pp.ray_dt, (void *)&pp.ray_pix,
                          (void *)&pp.n_active, (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
-                         (void *)&d_rgb, (void *)&d_stats, (void *)&taps };
+                         (void *)&d_rgb, (void *)&d_stats, (void *)&taps, (void *)&sweep_items_per_lane, (void *)&launch_seq };
         if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
         if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, lds, stream)) != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
