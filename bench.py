@@ -13,13 +13,13 @@ rays count, including the ones that miss the volume -- the reference's ms/frame 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`
 (one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE from the environment).  The path shards with no
 data-path collective: every rank holds a replica of the node array.
-  strong (what `auto` picks for N > 1) ONE sweep is split over the ranks: the rows of every frame in bands of 32
-         dealt out round-robin (--shard bands, the split that keeps every rank's load equal and the sharing of
-         traversals between iso values intact), contiguous blocks of rows (rows), or blocks of iso values (iso)
-  weak   each rank renders a whole sweep; the job is N sweeps
+  weak   (what `auto` picks) each rank renders a whole sweep of its own; the job is N sweeps
+  strong ONE sweep is split over the ranks: the rows of every frame in bands of 32 dealt out round-robin
+         (--shard bands, the split that keeps every rank's load equal and the sharing of traversals between iso
+         values intact), contiguous blocks of rows (rows), or blocks of iso values (iso)
 For N > 1 the line carries the main figure (`value`, the scaling named in `scaling`) and, unless --no-extras,
-the other ones measured in the same run: `weak_scaling`, and `strong_with_gather` (the split sweep with the
-framebuffers gathered to rank 0 over RCCL inside the timed region -- the one real exchange step).
+the other ones measured in the same run: `strong_scaling` (or `weak_scaling`), and `strong_with_gather` (the split
+sweep with the framebuffers gathered to rank 0 over RCCL inside the timed region -- the one real exchange step).
 
 Inputs (node array) and outputs (RGB24 frames) are resident in HBM across the timed region; `value_host_delivered`
 (N = 1) is the same sweep delivered into page-locked host memory by vr_render_sweep, which is what the
@@ -163,7 +163,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
-                    help="auto: strong for N > 1 (one sweep split over the ranks), with the weak figure as an extra")
+                    help="auto: weak (one sweep per rank), with the strong figures (one sweep split over the ranks) as extras")
     ap.add_argument("--shard", choices=["bands", "rows", "iso"], default="bands",
                     help="strong scaling: rows in bands of 32 dealt out round-robin (default), contiguous row blocks, or iso blocks")
     ap.add_argument("--gather", action="store_true", help="gather the framebuffers to rank 0 inside the timed region of the main figure")
@@ -207,7 +207,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+    # auto: every rank renders its own sweep (the units of the job are sharded over the ranks, nothing is exchanged:
+    # weak scaling), and the one-sweep-split-over-the-ranks figures ride along as extras in the same line
+    scaling = args.scaling if args.scaling != "auto" else "weak"
     if args.in_flight < 1 or (args.in_flight > 1 and (args.gather or world > 1)):
         raise SystemExit("--in-flight must be >= 1 and goes with one GPU and no gather")
 

@@ -6,9 +6,9 @@ export VR_BENCH_REHEARSAL=1
 out=gpurun_out/rehearsal
 mkdir -p $out
 i=0
-for args in "--gpus 2" "--gpus 4 --shard rows --gather --no-extras" "--gpus 3 --shard iso" "--gpus 2 --scaling weak --no-extras" \
-            "--gpus 4 --width 4096 --iso-begin 80 --iso-count 1 --gather --no-extras" \
-            "--gpus 2 --shard rows --volume gyroid1024 --width 2048 --iso-begin 140 --iso-count 1 --no-extras"; do
+for args in "--gpus 2" "--gpus 4 --scaling strong --shard rows --gather --no-extras" "--gpus 3 --scaling strong --shard iso" "--gpus 2 --scaling weak --no-extras" \
+            "--gpus 4 --scaling strong --width 4096 --iso-begin 80 --iso-count 1 --gather --no-extras" \
+            "--gpus 2 --scaling strong --shard rows --volume gyroid1024 --width 2048 --iso-begin 140 --iso-count 1 --no-extras"; do
   i=$((i+1))
   n=$(echo $args | cut -d' ' -f2)
   timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29500+i)) \
