@@ -109,12 +109,28 @@ static uint64_t div_check(uint64_t samples, uint64_t seed, uint32_t n_offsets)
 /* The iso sweep with traversals shared between iso values, as the sweep kernel does it, one pixel at a
  * time: trace the lowest open iso value while tracking the largest iso value with the same walk, give
  * the result to the whole interval, go on behind it.  `chunk` cuts the iso range into independent
- * pieces as the kernel does for load balance (0 = one piece).  Outputs are [iso_count][height][width]. */
+ * pieces as the kernel does for load balance (0 = one piece).  Outputs are [iso_count][height][width].
+ *
+ * `share` > 0 adds shared beginnings.  The walk for the next iso value, upper + 1, makes the same tests with
+ * the same outcomes as this one up to the first node whose bound equals `upper`; the reference returns to the root
+ * after every MOVE, so everything before the last such return ahead of that node -- ahead of the stretch of the walk
+ * in which `upper` last went down -- is shared, and the next walk can start from the lane's state at that return: t,
+ * cell, checks, moves and escape helps so far, and `upper` as it stood.  `share` such states are kept, newest on top:
+ * the older ones lie in the shared part, where they are the next walk's own.
+ * counts_out: [0] walks, [1] node reads, [2] the walks that carried on from a kept state. */
+namespace {
+struct CountingFetch {
+    const uint32_t *nodes;
+    uint64_t *count;
+    uint32_t operator()(uint32_t i) const { ++*count; return nodes[i]; }
+};
+} // namespace
+
 extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], const float src[3],
-                            const float forw[3], const float up[3], uint32_t width, uint32_t height, float viewport_width,
-                            uint32_t iso_begin, uint32_t iso_count, uint32_t chunk, uint32_t max_trips, uint8_t *gray,
-                            uint32_t *cell_flag, float *t_out, uint32_t *checked, uint32_t *node, uint64_t *sums /*[iso_count][7]*/,
-                            uint64_t *traces_out)
+                                   const float forw[3], const float up[3], uint32_t width, uint32_t height, float viewport_width,
+                                   uint32_t iso_begin, uint32_t iso_count, uint32_t chunk, uint32_t max_trips, uint32_t share,
+                                   uint8_t *gray, uint32_t *cell_flag, float *t_out, uint32_t *checked, uint32_t *node,
+                                   uint64_t *sums /*[iso_count][7]*/, uint64_t *counts_out /*[3]*/)
 {
     VrViewK k;
     k.ox = src[0]; k.oy = src[1]; k.oz = src[2];
@@ -133,7 +149,7 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
     std::memset(sums, 0, (size_t)iso_count * 7 * sizeof(uint64_t));
     const uint64_t frame = (uint64_t)width * height;
     if (chunk == 0) chunk = iso_count;
-    uint64_t traces = 0;
+    uint64_t f_test = 0, n_resumed = 0, n_fresh = 0;
     for (uint32_t yi = 0; yi < height; yi++)
         for (uint32_t xi = 0; xi < width; xi++) {
             const uint64_t pix = (uint64_t)yi * width + xi;
@@ -151,20 +167,40 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
             const uint32_t cell0 = L.cell;
             for (uint32_t c0 = 0; c0 < iso_count; c0 += chunk) {
                 const uint32_t last = iso_begin + (c0 + chunk < iso_count ? c0 + chunk : iso_count) - 1u;
+                struct Kept { uint32_t cell, checked, moves, esc, upper; float t; };
+                Kept kept[64];
+                uint32_t n_kept = 0;
                 for (uint32_t iso = iso_begin + c0; iso <= last;) {
-                    vr_lane_restart(L, st, k, ray.t, cell0);
                     VrIsoUpper track;
-                    track.upper = 255u;
                     uint32_t moves = 0, esc = 0, flag = 0;
+                    vr_lane_restart(L, st, k, ray.t, cell0);
+                    track.upper = 255u;
+                    if (share && n_kept) {
+                        const Kept s = kept[--n_kept];
+                        L.t = s.t; L.cell = s.cell; L.checked = s.checked;
+                        moves = s.moves; esc = s.esc;
+                        track.upper = s.upper;
+                        n_resumed++;
+                    } else {
+                        n_kept = 0;
+                        n_fresh++;
+                    }
+                    /* the lane's state at the last return to the root */
+                    Kept seg = { L.cell, L.checked, moves, esc, track.upper, L.t };
                     for (;;) {
-                        const uint32_t go = vr_lane_descend(L, iso, HostFetch{ nodes }, st, max_trips, track);
+                        const uint32_t go = vr_lane_descend(L, iso, CountingFetch{ nodes, &f_test }, st, max_trips, track);
                         if (go == VR_GO_MORE) continue;
+                        if (track.upper < seg.upper && share) { /* `upper` went down in the stretch that ends here */
+                            if (n_kept == share) { for (uint32_t q = 1; q < n_kept; q++) kept[q - 1] = kept[q]; n_kept--; }
+                            kept[n_kept++] = seg;
+                        }
                         if (go == VR_GO_HIT) { flag = 1; break; }
                         moves++;
+                        const uint32_t at_move = L.checked;
                         if (!vr_lane_move(L, k, esc)) break;
+                        seg = Kept{ L.cell, at_move, moves, esc, track.upper, L.t };
                         while (!vr_lane_pop(L, st, max_trips)) {}
                     }
-                    traces++;
                     const uint32_t e = track.upper < last ? track.upper : last;
                     for (uint32_t i = iso; i <= e; i++) {
                         const uint32_t j = i - iso_begin;
@@ -180,7 +216,7 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
                 }
             }
         }
-    if (traces_out) *traces_out = traces;
+    if (counts_out) { counts_out[0] = n_resumed + n_fresh; counts_out[1] = f_test; counts_out[2] = n_resumed; }
     return 0;
 }
 

@@ -71,15 +71,16 @@ def test_axis_parallel_rays_are_oob(oracle, emu_lib):
     assert (ref["cell_flag"][4, 4] >> 24) == 2  # the centre ray is exactly axis-parallel
 
 
-@pytest.mark.parametrize("chunk", [0, 32, 7])
-def test_shared_traversals_across_iso_values_equal_one_render_per_iso(oracle, emu_lib, c60_vox, c60_tree, chunk):
+@pytest.mark.parametrize("chunk,share", [(0, 0), (32, 0), (7, 0), (0, 2), (32, 2), (7, 1), (0, 8)])
+def test_shared_traversals_across_iso_values_equal_one_render_per_iso(oracle, emu_lib, c60_vox, c60_tree, chunk, share):
     """The sweep kernel traces a ray once per interval of iso values that cannot change any test outcome;
-    every per-iso output must still equal the oracle's separate render of that iso value, bit for bit."""
+    every per-iso output must still equal the oracle's separate render of that iso value, bit for bit.  With
+    `share` > 0 the walks of a ray also carry on from kept states of its earlier walks instead of the entry point."""
     from helpers import emu_sweep
     nodes, rd, _ = c60_tree
     pos, forw, up = oracle.main_camera(c60_vox.shape)
     W = H = 40
-    got = emu_sweep(emu_lib, nodes, rd, pos, forw, up, W, H, 2.0, 0, 256, chunk=chunk, max_trips=6)
+    got = emu_sweep(emu_lib, nodes, rd, pos, forw, up, W, H, 2.0, 0, 256, chunk=chunk, max_trips=6, share=share)
     n_active = 0
     for iso in range(256):
         ref = oracle.render(nodes, rd, pos, forw, up, W, H, 2.0, iso)
@@ -92,6 +93,10 @@ def test_shared_traversals_across_iso_values_equal_one_render_per_iso(oracle, em
                                                               st.escape_help_events, st.moves), iso
         n_active = W * H - st.oob_count
     assert got["traces"] < 256 * n_active / 3  # the sharing is real: far fewer traversals than ray x iso pairs
+    if share:
+        plain = emu_sweep(emu_lib, nodes, rd, pos, forw, up, W, H, 2.0, 0, 256, chunk=chunk, max_trips=6)
+        assert got["traces"] == plain["traces"] and got["carried_on"] > got["traces"] // 3
+        assert got["node_reads"] < 0.9 * plain["node_reads"]  # and so are the shared beginnings
 
 
 def test_shared_traversals_on_noise_and_partial_ranges(oracle, emu_lib):
@@ -100,8 +105,9 @@ def test_shared_traversals_on_noise_and_partial_ranges(oracle, emu_lib):
     vox = random_volume(rng, (9, 12, 7), "noise")
     nodes, rd, _ = oracle.build_kdt(vox, "AlwaysCenter")
     pos, forw, up = oracle.main_camera(vox.shape, (50.0, -120.0, 30.0))
-    for b, n, chunk in [(0, 256, 0), (17, 100, 16), (255, 1, 0), (200, 56, 5)]:
-        got = emu_sweep(emu_lib, nodes, rd, pos, forw, up, 24, 16, 0.15, b, n, chunk=chunk)
+    for b, n, chunk, share in [(0, 256, 0, 0), (17, 100, 16, 0), (255, 1, 0, 2), (200, 56, 5, 0), (0, 256, 0, 2), (17, 100, 16, 1),
+                               (3, 250, 40, 3)]:
+        got = emu_sweep(emu_lib, nodes, rd, pos, forw, up, 24, 16, 0.15, b, n, chunk=chunk, share=share)
         for j in range(n):
             ref = oracle.render(nodes, rd, pos, forw, up, 24, 16, 0.15, b + j)
             assert (got["gray"][j] == ref["rgb"][..., 0]).all() and (got["checked"][j] == ref["checked"]).all(), (b, j)

@@ -712,6 +712,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
 #ifndef VR_SWEEP_STEAL_MIN
 #define VR_SWEEP_STEAL_MIN 2
 #endif
+#ifndef VR_SWEEP_KEEP
+#define VR_SWEEP_KEEP 2 /* lane states kept for the next walks of the same ray to carry on from (0..2) */
+#endif
 /* once the queue is empty: hand-overs of half an iso range to an idle lane per wave and round, and the
  * shortest range (iso values behind the current one) worth splitting */
 constexpr uint32_t kSweepSteals = VR_SWEEP_STEALS, kSweepStealMin = VR_SWEEP_STEAL_MIN;
@@ -724,6 +727,19 @@ __host__ __device__ __forceinline__ uint32_t sweep_stat_words(uint32_t iso_count
     const uint32_t words = (2u + kSweepCounters) * (iso_count + 1u) + 1u; /* + the block's traversal count */
     return words + (words & 1u);
 }
+
+/* Shared beginnings of a ray's walks.  The walk for the next open iso value, upper + 1, makes the same tests with
+ * the same outcomes as the one just done up to the first node whose bound equals `upper`.  The reference returns to
+ * the root after every MOVE (src/raytrace.zig:246), so everything before the last such return ahead of that node --
+ * ahead of the stretch of the walk in which `upper` last went down -- is common to both, and the next walk may start
+ * from the lane's state at that return instead of from the ray's entry point: t, cell, and the checks, moves and escape
+ * helps so far, with `upper` as it stood there.  States older than that one lie in the common part, where they are the
+ * next walk's own, so a short stack of them (newest on top) serves a run of walks. */
+struct SweepKept {
+    float t;
+    uint32_t cell, checked, moves, esc, upper; /* upper = kNone: empty */
+    static constexpr uint32_t kNone = 0xffffffffu;
+};
 
 /* ---- the sweep kernel's lane code for the two tree formats ---- */
 struct WideFetch {
@@ -849,6 +865,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     WaveChunk chunk;
     VrIsoUpper track;
     track.upper = 255u;
+    SweepKept kept_a, kept_b; /* a: the newest */
+    kept_a.upper = kept_b.upper = SweepKept::kNone;
+    uint32_t seg_checked = 0, seg_upper = 255u; /* at the walk's last return to the root */
     uint32_t pix = 0, iso = 0, iso_last = 0, cell0 = 0, moves = 0, esc = 0;
     float t0 = 0.0f;
     bool alive = false, exhausted = false, popping = false;
@@ -872,6 +891,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 iso_last = iso_begin + (blk * block_isos + block_isos < iso_count ? blk * block_isos + block_isos : iso_count) - 1u;
                 track.upper = 255u;
                 moves = 0; esc = 0;
+                kept_a.upper = kept_b.upper = SweepKept::kNone;
+                seg_checked = 0; seg_upper = 255u;
                 alive = ray < n_active; /* the last group of 64 may be short */
                 popping = false;
             }
@@ -910,6 +931,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                     OPS::restart(L, stack, v, t0, cell0);
                     track.upper = 255u;
                     moves = 0; esc = 0;
+                    kept_a.upper = kept_b.upper = SweepKept::kNone;
+                    seg_checked = 0; seg_upper = 255u;
                     alive = true;
                     popping = false;
                 }
@@ -926,10 +949,18 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
             if (!popping) go = OPS::descend(L, v, iso, fetch, stack, track);
             bool done = false, hit = false;
             uint32_t err = 0;
+            if (VR_SWEEP_KEEP && go != VR_GO_MORE && track.upper < seg_upper) {
+                /* `upper` went down since the last return to the root: the state at that return is the newest one
+                 * the next walk shares (t, cell, moves and esc have not changed since) */
+                if (VR_SWEEP_KEEP > 1) kept_b = kept_a;
+                kept_a.t = L.t; kept_a.cell = OPS::cell(L); kept_a.checked = seg_checked;
+                kept_a.moves = moves; kept_a.esc = esc; kept_a.upper = seg_upper;
+            }
             if (go == VR_GO_HIT) {
                 done = true; hit = true;
             } else if (go == VR_GO_EXCLUDED) {
                 moves++;
+                seg_checked = L.checked; seg_upper = track.upper;
                 bool in_root = OPS::move(L, v, esc);
                 if (L.checked > VR_MAX_CHECKED) { in_root = false; err = 1; }
                 if (in_root) popping = true; else done = true; /* left the volume: a miss (src/raytrace.zig:66-68) */
@@ -971,10 +1002,15 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 iso = e + 1u;
                 if (iso > iso_last) {
                     alive = false;
-                } else { /* same ray, next open iso value */
-                    OPS::restart(L, stack, v, t0, cell0);
-                    track.upper = 255u;
-                    moves = 0; esc = 0;
+                } else { /* same ray, next open iso value: from the newest kept state, else from the entry point */
+                    const bool on = VR_SWEEP_KEEP && kept_a.upper != SweepKept::kNone;
+                    OPS::restart(L, stack, v, on ? kept_a.t : t0, on ? kept_a.cell : cell0);
+                    L.checked = on ? kept_a.checked : 0u;
+                    track.upper = on ? kept_a.upper : 255u;
+                    moves = on ? kept_a.moves : 0u; esc = on ? kept_a.esc : 0u;
+                    seg_checked = L.checked; seg_upper = track.upper;
+                    kept_a = kept_b;
+                    kept_b.upper = SweepKept::kNone;
                     popping = false;
                 }
             }
