@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--iso-begin", type=int, default=0)
     ap.add_argument("--iso-count", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle", type=int, default=24,
+                    help="at most this many extra untimed launches before the warm-up, ended as soon as the library has "
+                         "settled the sweep kernel's cut of the iso range for the workload (it tries a few per workload)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="independent steps in flight per rank (own context, stream and frame buffer each): with 2, the "
                          "tail of one sweep, where its last long rays leave CUs idle, overlaps the start of the next; "
@@ -302,6 +305,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    settled = [0]
+
     def measure(plan, gather, slots=None):
         """W warmup steps, then exactly K timed steps between barriers; returns (max-over-ranks seconds, rays per step
         of the whole job, kernel ms per launch on this rank)."""
@@ -316,6 +321,16 @@ def main():
                 if gather and world > 1:
                     plan.gather()
 
+        settle_steps = 0
+        if plan.rays and len(slots) == 1:
+            si = capi.SweepInfo()
+            for _ in range(args.settle):  # untimed, before the warm-up: the library tries its cuts of the iso range
+                step()
+                torch.cuda.synchronize()
+                settle_steps += 1
+                if L.vr_sweep_info_read(r.handle, C.byref(si)) != capi.VR_OK or si.cut_settled:
+                    break  # settled, or not a sweep-kernel workload: nothing to settle
+        settled[0] = settle_steps
         for _ in range(args.warmup):
             step()
             torch.cuda.synchronize()  # untimed; lets the library see each warm-up launch's report before the next one
@@ -355,6 +370,7 @@ def main():
         r2.set_kernel(args.kernel)
         slots.append((r2, torch.empty_like(main_plan.d_rgb), torch.zeros_like(main_plan.d_stats), torch.cuda.Stream()))
     dt, rays_per_step, kernel_ms, launches = measure(main_plan, args.gather, slots)
+    main_settle = settled[0]
 
     stats = main_plan.d_stats.cpu().numpy()
     nodes_checked = int(stats[:, 0].sum()) if main_plan.rays else 0
@@ -369,6 +385,7 @@ def main():
         if L.vr_sweep_info_read(r.handle, C.byref(si)) == capi.VR_OK and si.tick_end > si.tick_begin:
             span = float(si.tick_end - si.tick_begin)
             info = {"walks_per_launch": int(si.walks), "items_per_launch": int(si.items),
+                    "items_per_lane": int(si.items_per_lane), "cut_settled": bool(si.cut_settled), "settle_launches": main_settle,
                     "drain_frac": (si.tick_end - min(si.tick_queue_empty, si.tick_end)) / span,
                     "kernel_span_ms_gpu_clock": span / 1e5}
 

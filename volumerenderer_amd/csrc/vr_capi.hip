@@ -47,23 +47,27 @@ struct vr_ctx {
     size_t stats_cap = 0;
     void *d_tap[4] = { nullptr, nullptr, nullptr, nullptr };
     size_t tap_cap[4] = { 0, 0, 0, 0 };
+    uint32_t last_ipl = 0; /* items per lane of the last sweep-kernel launch */
     size_t info_off = 0; /* where the last sweep-kernel launch in d_work left its report; 0 = none yet */
     /* The sweep kernel's cut of the iso range, tuned per workload from its own reports.  Every sweep launch in the
      * context's scratch is tagged with a sequence number and followed by an asynchronous copy of its report into
-     * page-locked memory; a later launch reads whatever report has arrived (it never waits).  For a new workload
-     * (tree, image size, iso range) the default's report decides: a short tail (the queue ran empty late) means fewer,
-     * longer items would save re-walked traversals, a long tail asks for more, anything in between stays.  Up to two
-     * candidates on that side are then tried, each on ONE launch, all other launches using the best cut known; a
-     * candidate stays when its launch was at least 1.5 % shorter.  Results never depend on the cut. */
+     * page-locked memory; a later launch reads whatever report has arrived (it never waits).  Fewer, longer items
+     * share more of their walks and balance worse; where the best trade lies depends on the volume.  Single launches
+     * scatter by several per cent (which CU gets which item is decided by atomics), so a cut is judged by the shortest
+     * of three launches.  For a new workload (tree, image size, iso range) the default runs first (the very first
+     * launch, on cold caches, does not count), then the next smaller cut, and on from there while it pays; if the
+     * smaller cut did not pay, the next larger one, and on.  A candidate gets exactly three launches, all other launches
+     * use the best cut known; it stays when it was at least 1.5 % shorter.  Results never depend on the cut. */
     struct SweepTune {
         uint64_t key = 0;
         uint32_t seq = 0, seen = 0;
         uint32_t best_ipl = VR_SWEEP_ITEMS_DEFAULT;
         uint64_t best_span = 0;
-        uint32_t cand[2] = { 0, 0 };
-        int n_cand = 0, i_cand = 0;
-        int phase = 0;           /* 0 waiting for the default's report, 1 trying candidates, 2 settled */
-        bool cand_launched = false;
+        int dir = 0, step = 0;   /* candidate being tried: kSweepCuts[dir < 0 ? 0 : 1][step] */
+        int phase = 0;           /* 0 measuring the default, 1 trying candidates, 2 settled */
+        int n_launched = 0, n_reports = 0; /* of the cut being measured */
+        uint32_t last_seq = 0;             /* its newest launch */
+        uint64_t cur_span = ~0ull;         /* its shortest launch so far */
         uint32_t ipl_of_seq[16] = { 0 };
     } tune;
     uint64_t tree_id = 0;                 /* changes with every upload / build */
@@ -403,6 +407,8 @@ int vr_download_kdt_wide(vr_ctx *c, uint32_t *nodes_out, uint64_t first_slot, ui
 }
 
 /* Picks the sweep kernel's items-per-lane for this launch and tags it (see vr_ctx::SweepTune). */
+static constexpr int kSweepCutSteps = 2, kSweepSamples = 3;
+static constexpr uint32_t kSweepCuts[2][kSweepCutSteps] = { { 6u, 4u }, { 11u, 16u } }; /* below and above VR_SWEEP_ITEMS_DEFAULT */
 static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
                             uint32_t n_rows, uint32_t band_rows, uint32_t *ipl_out, uint32_t *seq_out)
 {
@@ -414,6 +420,7 @@ static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, 
     if (key != t.key) {
         t = vr_ctx::SweepTune();
         t.key = key;
+        c->h_info[5] = 0; /* a report of the previous workload must not be taken for one of this */
     }
     /* the newest report that has arrived */
     const unsigned long long *h = c->h_info;
@@ -426,23 +433,34 @@ static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, 
         if (tune_debug)
             std::fprintf(stderr, "[sweep tune] report of launch %u (now at %u): %u items per lane, span %.3f ms, tail %.3f, phase %d\n", got_seq,
                          t.seq, ipl, (double)span / 1e5, tail, t.phase);
-        if (t.phase == 0 && ipl == VR_SWEEP_ITEMS_DEFAULT) {
-            t.best_ipl = ipl; t.best_span = span;
-            if (tail < 0.25) { t.cand[0] = 9; t.cand[1] = 6; t.n_cand = 2; }
-            else if (tail > 0.40) { t.cand[0] = 16; t.cand[1] = 20; t.n_cand = 2; }
-            t.phase = t.n_cand ? 1 : 2;
-        } else if (t.phase == 1 && t.cand_launched && ipl == t.cand[t.i_cand]) {
-            const bool better = (double)span < 0.985 * (double)t.best_span;
-            if (better) { t.best_ipl = ipl; t.best_span = span; }
-            t.cand_launched = false;
-            if (better && t.i_cand + 1 < t.n_cand) t.i_cand++;
-            else t.phase = 2;
+        const uint32_t under_test = t.phase == 0 ? VR_SWEEP_ITEMS_DEFAULT : kSweepCuts[t.dir < 0 ? 0 : 1][t.step];
+        if (ipl == under_test && got_seq >= 2u) {
+            t.cur_span = span < t.cur_span ? span : t.cur_span;
+            t.n_reports++;
+        }
+        if (t.phase == 1 && t.n_launched == kSweepSamples && got_seq >= t.last_seq && t.n_reports < kSweepSamples)
+            t.n_launched = t.n_reports; /* reports overwritten before they were read (the host ran ahead): launch again */
+        if (t.n_reports == kSweepSamples) {
+            if (t.phase == 0) {
+                t.best_ipl = under_test; t.best_span = t.cur_span;
+                t.dir = -1; t.step = 0;
+                t.phase = 1;
+            } else {
+                const bool better = (double)t.cur_span < 0.985 * (double)t.best_span;
+                if (better) { t.best_ipl = under_test; t.best_span = t.cur_span; }
+                if (better && t.step + 1 < kSweepCutSteps) t.step++;           /* on in the same direction */
+                else if (!better && t.dir < 0 && t.step == 0) t.dir = 1;       /* smaller did not pay: try larger */
+                else t.phase = 2;
+            }
+            t.n_reports = 0; t.n_launched = 0; t.cur_span = ~0ull;
         }
     }
     uint32_t ipl = t.best_ipl;
-    if (t.phase == 1 && !t.cand_launched) { ipl = t.cand[t.i_cand]; t.cand_launched = true; } /* one launch per candidate */
+    const bool cand = t.phase == 1 && t.n_launched < kSweepSamples;
+    if (cand) { ipl = kSweepCuts[t.dir < 0 ? 0 : 1][t.step]; t.n_launched++; }
     t.seq++;
     if (t.seq == 0) t.seq = 1;
+    if (cand) t.last_seq = t.seq;
     t.ipl_of_seq[t.seq & 15u] = ipl;
     if (tune_debug) std::fprintf(stderr, "[sweep tune] launch %u: %u items per lane, phase %d\n", t.seq, ipl, t.phase);
     *ipl_out = ipl;
@@ -505,7 +523,9 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
     }
     const bool sweep_kernel = variant == VR_KERNEL_SWEEP || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u);
     uint32_t ipl = VR_SWEEP_ITEMS_DEFAULT, seq = 0;
-    if (sweep_kernel && !fixed_scratch) sweep_tune_next(c, view, iso_begin, iso_count, row_begin, row_end - row_begin, band_rows, &ipl, &seq);
+    static const uint32_t forced_ipl = std::getenv("VR_SWEEP_ITEMS") ? (uint32_t)std::atoi(std::getenv("VR_SWEEP_ITEMS")) : 0u; /* for tuning runs */
+    if (forced_ipl) ipl = forced_ipl;
+    else if (sweep_kernel && !fixed_scratch) sweep_tune_next(c, view, iso_begin, iso_count, row_begin, row_end - row_begin, band_rows, &ipl, &seq);
     if (c->wide)
         VR_HIP(vr_launch_render_wide(variant, s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
                                      (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq));
@@ -515,7 +535,8 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
     if (timing) c->ev_used += 2;
     if (sweep_kernel && !fixed_scratch) {
         c->info_off = vr_pipeline_info_offset(view->width, row_end - row_begin);
-        if (c->tune.phase != 2) /* the report follows the launch on its stream; the next launch reads it if it has arrived */
+        c->last_ipl = ipl;
+        if (c->tune.phase != 2 && !forced_ipl) /* the report follows the launch on its stream; the next launch reads it if it has arrived */
             VR_HIP(hipMemcpyAsync(c->h_info, (const char *)c->d_work + c->info_off, 48, hipMemcpyDeviceToHost, s));
     }
     return VR_OK;
@@ -803,7 +824,9 @@ int vr_sweep_info_read(vr_ctx *c, vr_sweep_info *out)
     if (!c->d_work || !c->info_off) return VR_ESTATE;
     VR_HIP(hipSetDevice(c->device));
     VR_HIP(hipStreamSynchronize(c->stream));
-    VR_HIP(hipMemcpy(out, (const char *)c->d_work + c->info_off, sizeof(*out), hipMemcpyDeviceToHost));
+    VR_HIP(hipMemcpy(out, (const char *)c->d_work + c->info_off, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    out->items_per_lane = c->last_ipl;
+    out->cut_settled = c->tune.phase == 2 ? 1u : 0u;
     return VR_OK;
 }
 

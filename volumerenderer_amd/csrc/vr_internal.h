@@ -31,7 +31,7 @@ enum {
 /* The sweep kernel cuts the iso range into as many blocks as it takes to have this many (ray, iso block) items per
  * lane of the grid: more blocks balance better, and every block re-walks its first traversal.  launch_seq tags the
  * launch in the kernel's report (0 = untagged). */
-#define VR_SWEEP_ITEMS_DEFAULT 12u
+#define VR_SWEEP_ITEMS_DEFAULT 8u
 
 /* Device scratch the pipeline variant needs for one call (ray list, tile offsets, queue heads). */
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count);

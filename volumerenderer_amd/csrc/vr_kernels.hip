@@ -713,7 +713,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
 #define VR_SWEEP_STEAL_MIN 2
 #endif
 #ifndef VR_SWEEP_KEEP
-#define VR_SWEEP_KEEP 2 /* lane states kept for the next walks of the same ray to carry on from (0..2) */
+#define VR_SWEEP_KEEP 2 /* lane states kept for the next walks of the same ray to carry on from */
 #endif
 /* once the queue is empty: hand-overs of half an iso range to an idle lane per wave and round, and the
  * shortest range (iso values behind the current one) worth splitting */
@@ -865,8 +865,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     WaveChunk chunk;
     VrIsoUpper track;
     track.upper = 255u;
-    SweepKept kept_a, kept_b; /* a: the newest */
-    kept_a.upper = kept_b.upper = SweepKept::kNone;
+    SweepKept kept[VR_SWEEP_KEEP + 1]; /* [0]: the newest; constant indices only, so these are registers */
+#pragma unroll
+    for (int q = 0; q <= VR_SWEEP_KEEP; q++) kept[q].upper = SweepKept::kNone;
     uint32_t seg_checked = 0, seg_upper = 255u; /* at the walk's last return to the root */
     uint32_t pix = 0, iso = 0, iso_last = 0, cell0 = 0, moves = 0, esc = 0;
     float t0 = 0.0f;
@@ -891,7 +892,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 iso_last = iso_begin + (blk * block_isos + block_isos < iso_count ? blk * block_isos + block_isos : iso_count) - 1u;
                 track.upper = 255u;
                 moves = 0; esc = 0;
-                kept_a.upper = kept_b.upper = SweepKept::kNone;
+#pragma unroll
+                for (int q = 0; q < VR_SWEEP_KEEP; q++) kept[q].upper = SweepKept::kNone;
                 seg_checked = 0; seg_upper = 255u;
                 alive = ray < n_active; /* the last group of 64 may be short */
                 popping = false;
@@ -931,7 +933,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                     OPS::restart(L, stack, v, t0, cell0);
                     track.upper = 255u;
                     moves = 0; esc = 0;
-                    kept_a.upper = kept_b.upper = SweepKept::kNone;
+#pragma unroll
+                    for (int q = 0; q < VR_SWEEP_KEEP; q++) kept[q].upper = SweepKept::kNone;
                     seg_checked = 0; seg_upper = 255u;
                     alive = true;
                     popping = false;
@@ -952,9 +955,10 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
             if (VR_SWEEP_KEEP && go != VR_GO_MORE && track.upper < seg_upper) {
                 /* `upper` went down since the last return to the root: the state at that return is the newest one
                  * the next walk shares (t, cell, moves and esc have not changed since) */
-                if (VR_SWEEP_KEEP > 1) kept_b = kept_a;
-                kept_a.t = L.t; kept_a.cell = OPS::cell(L); kept_a.checked = seg_checked;
-                kept_a.moves = moves; kept_a.esc = esc; kept_a.upper = seg_upper;
+#pragma unroll
+                for (int q = VR_SWEEP_KEEP - 1; q > 0; q--) kept[q] = kept[q - 1];
+                kept[0].t = L.t; kept[0].cell = OPS::cell(L); kept[0].checked = seg_checked;
+                kept[0].moves = moves; kept[0].esc = esc; kept[0].upper = seg_upper;
             }
             if (go == VR_GO_HIT) {
                 done = true; hit = true;
@@ -1003,14 +1007,14 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 if (iso > iso_last) {
                     alive = false;
                 } else { /* same ray, next open iso value: from the newest kept state, else from the entry point */
-                    const bool on = VR_SWEEP_KEEP && kept_a.upper != SweepKept::kNone;
-                    OPS::restart(L, stack, v, on ? kept_a.t : t0, on ? kept_a.cell : cell0);
-                    L.checked = on ? kept_a.checked : 0u;
-                    track.upper = on ? kept_a.upper : 255u;
-                    moves = on ? kept_a.moves : 0u; esc = on ? kept_a.esc : 0u;
+                    const bool on = VR_SWEEP_KEEP && kept[0].upper != SweepKept::kNone;
+                    OPS::restart(L, stack, v, on ? kept[0].t : t0, on ? kept[0].cell : cell0);
+                    L.checked = on ? kept[0].checked : 0u;
+                    track.upper = on ? kept[0].upper : 255u;
+                    moves = on ? kept[0].moves : 0u; esc = on ? kept[0].esc : 0u;
                     seg_checked = L.checked; seg_upper = track.upper;
-                    kept_a = kept_b;
-                    kept_b.upper = SweepKept::kNone;
+#pragma unroll
+                    for (int q = 0; q < VR_SWEEP_KEEP; q++) kept[q] = kept[q + 1]; /* [KEEP] stays empty */
                     popping = false;
                 }
             }
