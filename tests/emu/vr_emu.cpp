@@ -117,18 +117,27 @@ static uint64_t div_check(uint64_t samples, uint64_t seed, uint32_t n_offsets)
  * in which `upper` last went down -- is shared, and the next walk can start from the lane's state at that return: t,
  * cell, checks, moves and escape helps so far, and `upper` as it stood.  `share` such states are kept, newest on top:
  * the older ones lie in the shared part, where they are the next walk's own.
+ * `ahead` != 0: descents read both children of a node ahead of its test (vr_lane_descend_ahead).
  * counts_out: [0] walks, [1] node reads, [2] the walks that carried on from a kept state. */
 namespace {
 struct CountingFetch {
     const uint32_t *nodes;
     uint64_t *count;
+    uint32_t last_pair;
     uint32_t operator()(uint32_t i) const { ++*count; return nodes[i]; }
+    VrNodePair children(uint32_t g) const
+    {
+        uint32_t c = g << 1;
+        c = c < last_pair ? c : last_pair;
+        ++*count;
+        return VrNodePair{ nodes[c], nodes[c + 1] };
+    }
 };
 } // namespace
 
 extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], const float src[3],
                                    const float forw[3], const float up[3], uint32_t width, uint32_t height, float viewport_width,
-                                   uint32_t iso_begin, uint32_t iso_count, uint32_t chunk, uint32_t max_trips, uint32_t share,
+                                   uint32_t iso_begin, uint32_t iso_count, uint32_t chunk, uint32_t max_trips, uint32_t share, uint32_t ahead,
                                    uint8_t *gray, uint32_t *cell_flag, float *t_out, uint32_t *checked, uint32_t *node,
                                    uint64_t *sums /*[iso_count][7]*/, uint64_t *counts_out /*[3]*/)
 {
@@ -188,7 +197,9 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
                     /* the lane's state at the last return to the root */
                     Kept seg = { L.cell, L.checked, moves, esc, track.upper, L.t };
                     for (;;) {
-                        const uint32_t go = vr_lane_descend(L, iso, CountingFetch{ nodes, &f_test }, st, max_trips, track);
+                        const CountingFetch fetch{ nodes, &f_test, (uint32_t)(n_slots - 1u) & ~1u };
+                        const uint32_t go = ahead ? vr_lane_descend_ahead(L, iso, fetch, st, max_trips, track)
+                                                  : vr_lane_descend(L, iso, fetch, st, max_trips, track);
                         if (go == VR_GO_MORE) continue;
                         if (track.upper < seg.upper && share) { /* `upper` went down in the stretch that ends here */
                             if (n_kept == share) { for (uint32_t q = 1; q < n_kept; q++) kept[q - 1] = kept[q]; n_kept--; }

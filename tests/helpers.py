@@ -57,9 +57,9 @@ def emu_wide(L, nodes, rd, pos, f, u, w, h, vp, iso, pop_trips=0):
     return {"rgb": rgb, "cell_flag": cf, "t": tt, "checked": ck, "node": nd, "sums": sums}
 
 
-def emu_sweep(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, chunk=0, max_trips=64, share=0):
+def emu_sweep(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, chunk=0, max_trips=64, share=0, ahead=0):
     """The iso sweep with traversals shared between iso values, on the CPU (tests/emu/vr_emu.cpp); `share` = lane
-    states kept for later walks of the same ray to carry on from."""
+    states kept for later walks of the same ray to carry on from, `ahead` = descents that read both children ahead."""
     n_slots = len(nodes)
     rc, prep, _, _ = prepare_nodes(nodes, rd)
     assert rc == 0
@@ -74,7 +74,7 @@ def emu_sweep(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, chunk=0, 
     prep = np.ascontiguousarray(prep, dtype=np.uint32)
     L.vr_emu_sweep(C.c_void_p(prep.ctypes.data), C.c_uint64(n_slots), (C.c_uint8 * 3)(*[int(x) for x in rd]), f3(pos),
                    f3(f), f3(u), C.c_uint32(w), C.c_uint32(h), C.c_float(vp), C.c_uint32(iso_begin),
-                   C.c_uint32(iso_count), C.c_uint32(chunk), C.c_uint32(max_trips), C.c_uint32(share), C.c_void_p(gray.ctypes.data),
+                   C.c_uint32(iso_count), C.c_uint32(chunk), C.c_uint32(max_trips), C.c_uint32(share), C.c_uint32(ahead), C.c_void_p(gray.ctypes.data),
                    C.c_void_p(cf.ctypes.data), C.c_void_p(tt.ctypes.data), C.c_void_p(ck.ctypes.data),
                    C.c_void_p(nd.ctypes.data), C.c_void_p(sums.ctypes.data), C.c_void_p(counts.ctypes.data))
     return {"gray": gray, "cell_flag": cf, "t": tt, "checked": ck, "node": nd, "sums": sums, "traces": int(counts[0]),

@@ -71,8 +71,8 @@ def test_axis_parallel_rays_are_oob(oracle, emu_lib):
     assert (ref["cell_flag"][4, 4] >> 24) == 2  # the centre ray is exactly axis-parallel
 
 
-@pytest.mark.parametrize("chunk,share", [(0, 0), (32, 0), (7, 0), (0, 2), (32, 2), (7, 1), (0, 8)])
-def test_shared_traversals_across_iso_values_equal_one_render_per_iso(oracle, emu_lib, c60_vox, c60_tree, chunk, share):
+@pytest.mark.parametrize("chunk,share,ahead", [(0, 0, 0), (32, 0, 0), (7, 0, 1), (0, 2, 0), (32, 2, 1), (7, 1, 0), (0, 8, 1)])
+def test_shared_traversals_across_iso_values_equal_one_render_per_iso(oracle, emu_lib, c60_vox, c60_tree, chunk, share, ahead):
     """The sweep kernel traces a ray once per interval of iso values that cannot change any test outcome;
     every per-iso output must still equal the oracle's separate render of that iso value, bit for bit.  With
     `share` > 0 the walks of a ray also carry on from kept states of its earlier walks instead of the entry point."""
@@ -80,7 +80,7 @@ def test_shared_traversals_across_iso_values_equal_one_render_per_iso(oracle, em
     nodes, rd, _ = c60_tree
     pos, forw, up = oracle.main_camera(c60_vox.shape)
     W = H = 40
-    got = emu_sweep(emu_lib, nodes, rd, pos, forw, up, W, H, 2.0, 0, 256, chunk=chunk, max_trips=6, share=share)
+    got = emu_sweep(emu_lib, nodes, rd, pos, forw, up, W, H, 2.0, 0, 256, chunk=chunk, max_trips=6, share=share, ahead=ahead)
     n_active = 0
     for iso in range(256):
         ref = oracle.render(nodes, rd, pos, forw, up, W, H, 2.0, iso)
@@ -96,7 +96,8 @@ def test_shared_traversals_across_iso_values_equal_one_render_per_iso(oracle, em
     if share:
         plain = emu_sweep(emu_lib, nodes, rd, pos, forw, up, W, H, 2.0, 0, 256, chunk=chunk, max_trips=6)
         assert got["traces"] == plain["traces"] and got["carried_on"] > got["traces"] // 3
-        assert got["node_reads"] < 0.9 * plain["node_reads"]  # and so are the shared beginnings
+        if not ahead:
+            assert got["node_reads"] < 0.9 * plain["node_reads"]  # and so are the shared beginnings
 
 
 def test_shared_traversals_on_noise_and_partial_ranges(oracle, emu_lib):
@@ -107,7 +108,8 @@ def test_shared_traversals_on_noise_and_partial_ranges(oracle, emu_lib):
     pos, forw, up = oracle.main_camera(vox.shape, (50.0, -120.0, 30.0))
     for b, n, chunk, share in [(0, 256, 0, 0), (17, 100, 16, 0), (255, 1, 0, 2), (200, 56, 5, 0), (0, 256, 0, 2), (17, 100, 16, 1),
                                (3, 250, 40, 3)]:
-        got = emu_sweep(emu_lib, nodes, rd, pos, forw, up, 24, 16, 0.15, b, n, chunk=chunk, share=share)
+        got = emu_sweep(emu_lib, nodes, rd, pos, forw, up, 24, 16, 0.15, b, n, chunk=chunk, share=share, ahead=n & 1,
+                        max_trips=5 if share else 64)
         for j in range(n):
             ref = oracle.render(nodes, rd, pos, forw, up, 24, 16, 0.15, b + j)
             assert (got["gray"][j] == ref["rgb"][..., 0]).all() and (got["checked"][j] == ref["checked"]).all(), (b, j)

@@ -97,8 +97,10 @@ struct LdsStack {
  * low-word add cannot carry. */
 struct TopFetch {
     uint32_t g_lo, g_hi, l_lo, l_hi, n_top;
-    __device__ __forceinline__ TopFetch(const uint32_t *nodes, const uint32_t *lds_top, uint32_t n_top_)
+    uint32_t last_pair; /* the last even position whose right neighbour is still inside the array */
+    __device__ __forceinline__ TopFetch(const uint32_t *nodes, const uint32_t *lds_top, uint32_t n_top_, uint64_t n_slots = 1)
     {
+        last_pair = (uint32_t)(n_slots - 1u) & ~1u; /* positions 0 .. n_slots exist */
         const uint64_t ga = (uint64_t)(uintptr_t)nodes, la = (uint64_t)(uintptr_t)(const void *)lds_top;
         g_lo = (uint32_t)ga; g_hi = (uint32_t)(ga >> 32);
         l_lo = (uint32_t)la; l_hi = (uint32_t)(la >> 32);
@@ -113,6 +115,19 @@ struct TopFetch {
         const uint32_t lo = (top ? l_lo : g_lo) + (g << 2);
         const uint32_t hi = top ? l_hi : g_hi;
         return *(const uint32_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    }
+    /* the words at 2g and 2g + 1 in one 8-byte read (both arrays are 8-byte aligned, n_top is a power of two, so a
+     * pair lies in one of them); for a node of the last level -- a leaf, whose children nobody uses -- the last pair
+     * of the array instead */
+    __device__ __forceinline__ VrNodePair children(uint32_t g) const
+    {
+        uint32_t c = g << 1;
+        c = c < last_pair ? c : last_pair;
+        const bool top = c < n_top;
+        const uint32_t lo = (top ? l_lo : g_lo) + (c << 2);
+        const uint32_t hi = top ? l_hi : g_hi;
+        const uint2 w = *(const uint2 *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+        return VrNodePair{ w.x, w.y };
     }
 };
 
@@ -764,13 +779,17 @@ struct SweepNarrow {
     typedef TopFetch Fetch;
     static constexpr uint32_t kFlagShift = 24u;
     __device__ static __forceinline__ Store store(uint32_t *) { return Store(); }
-    __device__ static __forceinline__ Fetch fetch(const uint32_t *nodes, const uint32_t *s_top, uint32_t n_top) { return TopFetch(nodes, s_top, n_top); }
+    __device__ static __forceinline__ Fetch fetch(const uint32_t *nodes, const uint32_t *s_top, uint32_t n_top, uint64_t n_slots) { return TopFetch(nodes, s_top, n_top, n_slots); }
     __device__ static __forceinline__ void begin(Lane &L, Store &st, const VrViewK &v, float dx, float dy, float dz, float t) { vr_lane_begin(L, st, v, dx, dy, dz, t); }
     __device__ static __forceinline__ uint32_t cell(const Lane &L) { return L.cell; }
     __device__ static __forceinline__ void restart(Lane &L, Store &st, const VrViewK &v, float t0, uint32_t c0) { vr_lane_restart(L, st, v, t0, c0); }
     __device__ static __forceinline__ uint32_t descend(Lane &L, const VrViewK &, uint32_t iso, const Fetch &f, Store &st, VrIsoUpper &track)
     {
+#ifdef VR_SWEEP_NO_AHEAD
         return vr_lane_descend(L, iso, f, st, kSweepDescendTrips, track);
+#else
+        return vr_lane_descend_ahead(L, iso, f, st, kSweepDescendTrips, track);
+#endif
     }
     __device__ static __forceinline__ bool move(Lane &L, const VrViewK &v, uint32_t &esc) { return vr_lane_move(L, v, esc); }
     __device__ static __forceinline__ bool pop(Lane &L, Store &st) { return vr_lane_pop(L, st, kSweepPopTrips); }
@@ -793,7 +812,7 @@ struct SweepWide {
     typedef WideFetch Fetch;
     static constexpr uint32_t kFlagShift = VR_WIDE_FLAG_SHIFT;
     __device__ static __forceinline__ Store store(uint32_t *s_dyn) { return Store{ s_dyn + threadIdx.x }; }
-    __device__ static __forceinline__ Fetch fetch(const uint32_t *nodes, const uint32_t *, uint32_t) { return WideFetch{ nodes }; }
+    __device__ static __forceinline__ Fetch fetch(const uint32_t *nodes, const uint32_t *, uint32_t, uint64_t) { return WideFetch{ nodes }; }
     __device__ static __forceinline__ void begin(Lane &L, Store &, const VrViewK &v, float dx, float dy, float dz, float t) { vr_wide_begin(L, v, dx, dy, dz, t); }
     __device__ static __forceinline__ uint32_t cell(const Lane &L) { return L.c; }
     __device__ static __forceinline__ void restart(Lane &L, Store &, const VrViewK &v, float t0, uint32_t c0) { vr_wide_restart(L, v, t0, c0); }
@@ -834,7 +853,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_top[i] = nodes[i];
     __syncthreads();
     typename OPS::Store stack = OPS::store(s_dyn);
-    const typename OPS::Fetch fetch = OPS::fetch(nodes, s_top, n_top);
+    const typename OPS::Fetch fetch = OPS::fetch(nodes, s_top, n_top, v.n_slots);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_active = *n_active_ptr;

@@ -410,6 +410,40 @@ VR_HD uint32_t vr_lane_descend(VrLane &L, uint32_t iso, const Fetch &fetch, Stac
     return vr_lane_descend(L, iso, fetch, stack, max_trips, none);
 }
 
+/* vr_lane_descend with the node reads taken off the lane's critical path: the two children of a node are neighbours
+ * in the heap (positions 2g and 2g + 1), so both words are requested with one 8-byte read as soon as the node itself is
+ * known, and the read is under way while the node's range test, the child choice and the box update are worked out.
+ * fetch.children(g) returns the words at 2g and 2g + 1 (any two words when the node has no children: they are not
+ * used then).  Same results as vr_lane_descend. */
+struct VrNodePair { uint32_t left, right; };
+
+template <class Fetch, class Stack, class Track>
+VR_HD uint32_t vr_lane_descend_ahead(VrLane &L, uint32_t iso, const Fetch &fetch, Stack &stack, uint32_t max_trips, Track &track)
+{
+    const uint32_t d0 = stack.depth();
+    uint32_t out = VR_GO_MORE;
+    uint32_t n = fetch(L.g);
+    for (uint32_t trip = 0; trip < max_trips; trip++) {
+        VrNodePair kids = { 0u, 0u };
+        if (trip + 1u < max_trips) kids = fetch.children(L.g); /* the last trip's child is read by the next call */
+        const bool holds = vr_node_holds(n, iso);
+        if (!holds) { track.excluded(n, iso); out = VR_GO_EXCLUDED; break; }
+        track.passed(n);
+        if (n & VR_N_LEAF) { out = VR_GO_HIT; break; }
+        const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
+        const bool right = ((L.cell >> sh) & 0xffu) >= part;
+        uint32_t side = right ? L.lo : L.hi;
+        stack.push(side);
+        side = (side & ~(0xffu << sh)) | (part << sh);
+        L.lo = right ? side : L.lo;
+        L.hi = right ? L.hi : side;
+        L.g = vr_twice_plus(L.g, right);
+        n = right ? kids.right : kids.left;
+    }
+    L.checked += stack.depth() - d0 + (out != VR_GO_MORE ? 1u : 0u);
+    return out;
+}
+
 /* Puts a lane back at the entry point of its ray (for the next iso value of a sweep): everything
  * vr_lane_begin derives from the direction alone is kept. */
 template <class Stack>
