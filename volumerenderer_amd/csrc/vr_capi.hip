@@ -54,16 +54,17 @@ struct vr_ctx {
      * page-locked memory; a later launch reads whatever report has arrived (it never waits).  Fewer, longer items
      * share more of their walks and balance worse; where the best trade lies depends on the volume.  Single launches
      * scatter by several per cent (which CU gets which item is decided by atomics), so a cut is judged by the shortest
-     * of three launches.  For a new workload (tree, image size, iso range) the default runs first (the very first
-     * launch, on cold caches, does not count), then the next smaller cut, and on from there while it pays; if the
-     * smaller cut did not pay, the next larger one, and on.  A candidate gets exactly three launches, all other launches
+     * of three launches.  For a new workload (tree, image size, iso range) the base cut runs first (8 items per lane
+     * for long sweeps, fewer for short ones: sweep_cut_base; the very first launch, on cold caches, does not count),
+     * then the next smaller cut (3/4, 1/2, 1/4 of the base), and on from there while it pays; if the smaller cut did
+     * not pay, the next larger one (11/8, 2x), and on.  A candidate gets exactly three launches, all other launches
      * use the best cut known; it stays when it was at least 1.5 % shorter.  Results never depend on the cut. */
     struct SweepTune {
         uint64_t key = 0;
         uint32_t seq = 0, seen = 0;
-        uint32_t best_ipl = VR_SWEEP_ITEMS_DEFAULT;
+        uint32_t base = VR_SWEEP_ITEMS_DEFAULT, best_ipl = VR_SWEEP_ITEMS_DEFAULT;
         uint64_t best_span = 0;
-        int dir = 0, step = 0;   /* candidate being tried: kSweepCuts[dir < 0 ? 0 : 1][step] */
+        int dir = 0, step = 0;   /* candidate being tried: sweep_cut_candidate(base, dir, step) */
         int phase = 0;           /* 0 measuring the default, 1 trying candidates, 2 settled */
         int n_launched = 0, n_reports = 0; /* of the cut being measured */
         uint32_t last_seq = 0;             /* its newest launch */
@@ -407,8 +408,22 @@ int vr_download_kdt_wide(vr_ctx *c, uint32_t *nodes_out, uint64_t first_slot, ui
 }
 
 /* Picks the sweep kernel's items-per-lane for this launch and tags it (see vr_ctx::SweepTune). */
-static constexpr int kSweepCutSteps = 2, kSweepSamples = 3;
-static constexpr uint32_t kSweepCuts[2][kSweepCutSteps] = { { 6u, 4u }, { 11u, 16u } }; /* below and above VR_SWEEP_ITEMS_DEFAULT */
+static constexpr int kSweepSamples = 3;
+/* where the search starts: short sweeps have few distinct walks per ray to share, and every cut costs one more */
+static uint32_t sweep_cut_base(uint32_t iso_count)
+{
+    const uint32_t b = iso_count / 8u;
+    return b < 2u ? 2u : (b > VR_SWEEP_ITEMS_DEFAULT ? VR_SWEEP_ITEMS_DEFAULT : b);
+}
+/* the step-th candidate below (dir < 0: 3/4, 1/2, 1/4 of the base) or above it (11/8, 2x); 0 = none left */
+static uint32_t sweep_cut_candidate(uint32_t base, int dir, int step)
+{
+    static const uint32_t num[2][3] = { { 6u, 4u, 2u }, { 11u, 16u, 0u } };
+    if (step > 2 || num[dir < 0 ? 0 : 1][step] == 0u) return 0u;
+    const uint32_t c = (base * num[dir < 0 ? 0 : 1][step] + 4u) / 8u;
+    const uint32_t prev = step == 0 ? base : (base * num[dir < 0 ? 0 : 1][step - 1] + 4u) / 8u;
+    return c == prev || c == 0u ? 0u : c;
+}
 static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
                             uint32_t n_rows, uint32_t band_rows, uint32_t *ipl_out, uint32_t *seq_out)
 {
@@ -420,6 +435,7 @@ static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, 
     if (key != t.key) {
         t = vr_ctx::SweepTune();
         t.key = key;
+        t.base = t.best_ipl = sweep_cut_base(iso_count);
         c->h_info[5] = 0; /* a report of the previous workload must not be taken for one of this */
     }
     /* the newest report that has arrived */
@@ -433,7 +449,7 @@ static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, 
         if (tune_debug)
             std::fprintf(stderr, "[sweep tune] report of launch %u (now at %u): %u items per lane, span %.3f ms, tail %.3f, phase %d\n", got_seq,
                          t.seq, ipl, (double)span / 1e5, tail, t.phase);
-        const uint32_t under_test = t.phase == 0 ? VR_SWEEP_ITEMS_DEFAULT : kSweepCuts[t.dir < 0 ? 0 : 1][t.step];
+        const uint32_t under_test = t.phase == 0 ? t.base : sweep_cut_candidate(t.base, t.dir, t.step);
         if (ipl == under_test && got_seq >= 2u) {
             t.cur_span = span < t.cur_span ? span : t.cur_span;
             t.n_reports++;
@@ -443,21 +459,22 @@ static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, 
         if (t.n_reports == kSweepSamples) {
             if (t.phase == 0) {
                 t.best_ipl = under_test; t.best_span = t.cur_span;
-                t.dir = -1; t.step = 0;
+                t.dir = sweep_cut_candidate(t.base, -1, 0) ? -1 : 1; t.step = 0;
                 t.phase = 1;
             } else {
                 const bool better = (double)t.cur_span < 0.985 * (double)t.best_span;
                 if (better) { t.best_ipl = under_test; t.best_span = t.cur_span; }
-                if (better && t.step + 1 < kSweepCutSteps) t.step++;           /* on in the same direction */
-                else if (!better && t.dir < 0 && t.step == 0) t.dir = 1;       /* smaller did not pay: try larger */
+                if (better && sweep_cut_candidate(t.base, t.dir, t.step + 1)) t.step++; /* on in the same direction */
+                else if (!better && t.dir < 0 && t.step == 0) t.dir = 1;                /* smaller did not pay: try larger */
                 else t.phase = 2;
             }
+            if (t.phase == 1 && !sweep_cut_candidate(t.base, t.dir, t.step)) t.phase = 2;
             t.n_reports = 0; t.n_launched = 0; t.cur_span = ~0ull;
         }
     }
     uint32_t ipl = t.best_ipl;
     const bool cand = t.phase == 1 && t.n_launched < kSweepSamples;
-    if (cand) { ipl = kSweepCuts[t.dir < 0 ? 0 : 1][t.step]; t.n_launched++; }
+    if (cand) { ipl = sweep_cut_candidate(t.base, t.dir, t.step); t.n_launched++; }
     t.seq++;
     if (t.seq == 0) t.seq = 1;
     if (cand) t.last_seq = t.seq;
@@ -522,7 +539,7 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         ev1 = c->ev[c->ev_used + 1];
     }
     const bool sweep_kernel = variant == VR_KERNEL_SWEEP || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u);
-    uint32_t ipl = VR_SWEEP_ITEMS_DEFAULT, seq = 0;
+    uint32_t ipl = sweep_cut_base(iso_count), seq = 0; /* the no-allocation entry point stays on this */
     static const uint32_t forced_ipl = std::getenv("VR_SWEEP_ITEMS") ? (uint32_t)std::atoi(std::getenv("VR_SWEEP_ITEMS")) : 0u; /* for tuning runs */
     if (forced_ipl) ipl = forced_ipl;
     else if (sweep_kernel && !fixed_scratch) sweep_tune_next(c, view, iso_begin, iso_count, row_begin, row_end - row_begin, band_rows, &ipl, &seq);
