@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
     for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_top[i] = nodes[i];
     __syncthreads();
     LdsStack<kTraceThreads> stack;
-    const TopFetch fetch(nodes, s_top, n_top);
+    const TopFetch fetch(nodes, s_top, n_top, v.n_slots);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_active = *n_active_ptr;
@@ -602,7 +602,11 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
 #ifdef VR_DIAG
                     d_trips = stack.depth();
 #endif
+#ifdef VR_TRACE_NO_AHEAD
                     go = vr_lane_descend(L, iso, fetch, stack, kDescendTrips);
+#else
+                    { VrNoIsoTrack none; go = vr_lane_descend_ahead(L, iso, fetch, stack, kDescendTrips, none); }
+#endif
 #ifdef VR_DIAG
                     d_trips = stack.depth() - d_trips + (go != VR_GO_MORE ? 1u : 0u);
 #endif
