@@ -235,6 +235,17 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
 #include "../../volumerenderer_amd/csrc/vr_trace_wide.h"
 
 namespace {
+struct HostWidePairs { /* children(i): the words at 2i + 1 and 2i + 2, clamped to the array as on the device */
+    const uint32_t *nodes;
+    uint32_t last_pair;
+    uint32_t operator()(uint32_t i) const { return nodes[i]; }
+    VrNodePair children(uint32_t i) const
+    {
+        uint32_t c = 2u * i + 1u;
+        c = c < last_pair ? c : last_pair;
+        return VrNodePair{ nodes[c], nodes[c + 1] };
+    }
+};
 struct HostPath {
     uint32_t word[VR_WIDE_MAX_DEPTH];
     uint32_t get(uint32_t d) const { return word[d]; }
@@ -244,7 +255,7 @@ struct HostPath {
 
 extern "C" int vr_emu_wide(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3], const float src[3],
                            const float forw[3], const float up[3], uint32_t width, uint32_t height,
-                           float viewport_width, uint32_t iso, uint32_t pop_trips, uint8_t *rgb, uint32_t *cell_flag,
+                           float viewport_width, uint32_t iso, uint32_t pop_trips, uint32_t ahead_trips, uint8_t *rgb, uint32_t *cell_flag,
                            float *t_out, uint32_t *checked, uint32_t *node, uint64_t *sums /*7*/)
 {
     VrViewK k;
@@ -266,7 +277,7 @@ extern "C" int vr_emu_wide(const uint32_t *nodes, uint64_t n_slots, const uint16
         for (uint32_t xi = 0; xi < width; xi++) {
             VrRay ray = vr_make_ray(k, xi, yi);
             HostPath path;
-            VrHit h = vr_trace_wide(k, ray, iso, HostFetch{ nodes }, path, pop_trips ? pop_trips : 64u);
+            VrHit h = vr_trace_wide(k, ray, iso, HostWidePairs{ nodes, (uint32_t)(n_slots - 2u) }, path, pop_trips ? pop_trips : 64u, ahead_trips);
             uint64_t pix = (uint64_t)yi * width + xi;
             uint8_t g = h.flag == 1u ? vr_shade(h.t) : 0;
             rgb[pix * 3] = rgb[pix * 3 + 1] = rgb[pix * 3 + 2] = g;

@@ -39,7 +39,7 @@ def emu_render(L, variant, nodes, rd, pos, f, u, w, h, vp, iso):
     return {"rgb": rgb, "cell_flag": cf, "t": tt, "checked": ck, "node": nd, "sums": sums}
 
 
-def emu_wide(L, nodes, rd, pos, f, u, w, h, vp, iso, pop_trips=0):
+def emu_wide(L, nodes, rd, pos, f, u, w, h, vp, iso, pop_trips=0, ahead_trips=0):
     """The resume traversal of wide volumes (vr_trace_wide.h) on the CPU, on wide node words; pop_trips bounds every
     pop phase as the persistent kernel does (0 = unbounded)."""
     rgb = np.zeros((h, w, 3), np.uint8)
@@ -52,7 +52,7 @@ def emu_wide(L, nodes, rd, pos, f, u, w, h, vp, iso, pop_trips=0):
     nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
     L.vr_emu_wide(C.c_void_p(nodes.ctypes.data), C.c_uint64(len(nodes)), (C.c_uint16 * 3)(*[int(x) for x in rd]),
                   f3(pos), f3(f), f3(u), C.c_uint32(w), C.c_uint32(h), C.c_float(vp), C.c_uint32(iso),
-                  C.c_uint32(pop_trips), C.c_void_p(rgb.ctypes.data), C.c_void_p(cf.ctypes.data), C.c_void_p(tt.ctypes.data),
+                  C.c_uint32(pop_trips), C.c_uint32(ahead_trips), C.c_void_p(rgb.ctypes.data), C.c_void_p(cf.ctypes.data), C.c_void_p(tt.ctypes.data),
                   C.c_void_p(ck.ctypes.data), C.c_void_p(nd.ctypes.data), C.c_void_p(sums.ctypes.data))
     return {"rgb": rgb, "cell_flag": cf, "t": tt, "checked": ck, "node": nd, "sums": sums}
 

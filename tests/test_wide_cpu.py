@@ -64,9 +64,9 @@ def test_wide_lane_code_matches_wide_oracle(oracle, emu_lib, shape, kind):
         for vp in (0.2, 3.0):
             for iso in (0, 90, 200):
                 ref = oracle.render(nodes, rd, pos, forw, up, 48, 40, vp, iso, wide=True)
-                for pop_trips in (0, 1, 3):
-                    got = emu_wide(emu_lib, nodes, rd, pos, forw, up, 48, 40, vp, iso, pop_trips)
-                    assert_same_render(got, ref, "%s %s iso %d pop bound %d" % (shape, pos, iso, pop_trips))
+                for pop_trips, ahead_trips in ((0, 0), (1, 0), (3, 0), (3, 6), (0, 1), (0, 2)):
+                    got = emu_wide(emu_lib, nodes, rd, pos, forw, up, 48, 40, vp, iso, pop_trips, ahead_trips)
+                    assert_same_render(got, ref, "%s %s iso %d pop bound %d, reading ahead %d" % (shape, pos, iso, pop_trips, ahead_trips))
                     assert int(got["sums"][0]) == ref["stats"].nodes_checked and int(got["sums"][6]) == 0
                 hits += ref["stats"].hit_count
     assert hits > 0

@@ -763,7 +763,17 @@ struct SweepKept {
 /* ---- the sweep kernel's lane code for the two tree formats ---- */
 struct WideFetch {
     const uint32_t *nodes;
+    uint32_t last_pair; /* the last index whose right neighbour is still inside the array */
     __device__ __forceinline__ uint32_t operator()(uint32_t idx) const { return nodes[idx]; }
+    /* the words at 2i + 1 and 2i + 2 in one 8-byte read (4-byte aligned) */
+    __device__ __forceinline__ VrNodePair children(uint32_t idx) const
+    {
+        struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
+        uint32_t c = 2u * idx + 1u;
+        c = c < last_pair ? c : last_pair;
+        const Pair w = *(const Pair *)(nodes + c);
+        return VrNodePair{ w.a, w.b };
+    }
 };
 
 template <uint32_t STRIDE>
@@ -816,13 +826,17 @@ struct SweepWide {
     typedef WideFetch Fetch;
     static constexpr uint32_t kFlagShift = VR_WIDE_FLAG_SHIFT;
     __device__ static __forceinline__ Store store(uint32_t *s_dyn) { return Store{ s_dyn + threadIdx.x }; }
-    __device__ static __forceinline__ Fetch fetch(const uint32_t *nodes, const uint32_t *, uint32_t, uint64_t) { return WideFetch{ nodes }; }
+    __device__ static __forceinline__ Fetch fetch(const uint32_t *nodes, const uint32_t *, uint32_t, uint64_t n_slots) { return WideFetch{ nodes, n_slots >= 2u ? (uint32_t)(n_slots - 2u) : 0u }; }
     __device__ static __forceinline__ void begin(Lane &L, Store &, const VrViewK &v, float dx, float dy, float dz, float t) { vr_wide_begin(L, v, dx, dy, dz, t); }
     __device__ static __forceinline__ uint32_t cell(const Lane &L) { return L.c; }
     __device__ static __forceinline__ void restart(Lane &L, Store &, const VrViewK &v, float t0, uint32_t c0) { vr_wide_restart(L, v, t0, c0); }
     __device__ static __forceinline__ uint32_t descend(Lane &L, const VrViewK &v, uint32_t iso, const Fetch &f, Store &st, VrIsoUpper &track)
     {
+#ifdef VR_WIDE_NO_AHEAD
         return vr_wide_descend(L, v, iso, f, st, kSweepDescendTrips, track);
+#else
+        return vr_wide_descend_ahead(L, v, iso, f, st, kSweepDescendTrips, track);
+#endif
     }
     __device__ static __forceinline__ bool move(Lane &L, const VrViewK &v, uint32_t &esc) { return vr_wide_move(L, v, esc); }
     __device__ static __forceinline__ bool pop(Lane &L, Store &st) { return vr_wide_pop(L, st, kSweepPopTrips); }
@@ -1128,7 +1142,7 @@ __global__ __launch_bounds__(256) void vr_k_render_wide(VrViewK v, const uint32_
     if (valid) {
         const VrRay ray = vr_make_ray(v, xi, row_begin + vr_band_row(v, yr));
         LdsPath<256u> path{ s_path + threadIdx.x };
-        h = vr_trace_wide(v, ray, iso, WideFetch{ nodes }, path);
+        h = vr_trace_wide(v, ray, iso, WideFetch{ nodes, 0u }, path);
         const uint64_t pix = ((uint64_t)blockIdx.y * n_rows + yr) * v.width + xi;
         const uint8_t g = h.flag == VR_FLAG_HIT ? vr_shade(h.t) : (uint8_t)0;
         rgb[pix * 3 + 0] = g;
@@ -1189,7 +1203,7 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
 {
     extern __shared__ uint32_t s_dyn[];
     LdsPath<kWideThreads> path{ s_dyn + threadIdx.x };
-    const WideFetch fetch{ nodes };
+    const WideFetch fetch{ nodes, (uint32_t)(v.n_slots - 2u) }; /* a wide tree has far more than two nodes */
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_active = *n_active_ptr;
@@ -1244,7 +1258,11 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
 
             if (alive) {
                 uint32_t go = VR_GO_MORE;
+#ifdef VR_WIDE_NO_AHEAD
                 if (!popping) go = vr_wide_descend(L, v, iso, fetch, path, VR_WIDE_DESCEND_TRIPS);
+#else
+                if (!popping) { VrNoIsoTrack none; go = vr_wide_descend_ahead(L, v, iso, fetch, path, VR_WIDE_DESCEND_TRIPS, none); }
+#endif
 #ifdef VR_DIAG
                 d_go = go;
 #endif

@@ -113,6 +113,31 @@ VR_HD uint32_t vr_wide_descend(VrWideLane &L, const VrViewK &v, uint32_t iso, co
     return vr_wide_descend(L, v, iso, fetch, path, max_trips, none);
 }
 
+/* vr_wide_descend with the node reads taken off the critical path: both children of a node (heap neighbours
+ * 2i + 1, 2i + 2) are requested with one 8-byte read as soon as the node is known (see vr_lane_descend_ahead).
+ * fetch.children(i) returns those two words (any two when the node has no children).  Same results. */
+template <class NodeFetch, class Path, class Track>
+VR_HD uint32_t vr_wide_descend_ahead(VrWideLane &L, const VrViewK &v, uint32_t iso, const NodeFetch &fetch, Path &path,
+                                     uint32_t max_trips, Track &track)
+{
+    uint32_t n = fetch(L.idx);
+    for (uint32_t trip = 0; trip < max_trips; trip++) {
+        VrNodePair kids = { 0u, 0u };
+        if (trip + 1u < max_trips) kids = fetch.children(L.idx);
+        L.checked++;
+        const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
+        if (!(mn <= iso && iso <= mx)) { track.excluded(n, iso); return VR_GO_EXCLUDED; }
+        track.passed(n);
+        if (L.hi - L.lo == VR_F_ONES) return VR_GO_HIT;
+        const uint32_t axis = VR_WIDE_AXIS(n), part = VR_WIDE_PART(n);
+        const uint32_t word = vr_wide_split(L, part, axis, axis * 10u);
+        path.set(L.d, word);
+        L.d++;
+        n = (word & (1u << 17)) ? kids.right : kids.left;
+    }
+    return VR_GO_MORE;
+}
+
 /* Puts a lane back at the entry point of its ray (for the next iso value of a sweep). */
 VR_HD void vr_wide_restart(VrWideLane &L, const VrViewK &v, float t_entry, uint32_t cell_entry)
 {
@@ -198,7 +223,7 @@ VR_HD bool vr_wide_pop(VrWideLane &L, Path &path, uint32_t max_trips)
 /* one whole ray */
 template <class NodeFetch, class Path>
 VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Path &path,
-                          uint32_t pop_trips = 64u)
+                          uint32_t pop_trips = 64u, uint32_t ahead_trips = 0u)
 {
     VrHit h;
     h.t = 0.0f; h.flag = 2u; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
@@ -207,7 +232,13 @@ VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, Node
     vr_wide_begin(L, v, ray.dx, ray.dy, ray.dz, ray.t);
     h.flag = 0u;
     for (;;) {
-        const uint32_t go = vr_wide_descend(L, v, iso, fetch, path, VR_WIDE_MAX_DEPTH + 1u);
+        uint32_t go;
+        if (ahead_trips) { /* the bounded, reading-ahead descents of the persistent kernels */
+            VrNoIsoTrack none;
+            do go = vr_wide_descend_ahead(L, v, iso, fetch, path, ahead_trips, none); while (go == VR_GO_MORE);
+        } else {
+            go = vr_wide_descend(L, v, iso, fetch, path, VR_WIDE_MAX_DEPTH + 1u);
+        }
         if (go == VR_GO_HIT) { h.flag = 1u; h.node = L.idx; h.cell = L.c; break; }
         if (L.checked > VR_MAX_CHECKED) { h.error = 1; break; } /* safety valve, never reached on a valid tree */
         h.moves++;
