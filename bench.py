@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--iso-begin", type=int, default=0)
     ap.add_argument("--iso-count", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-delivered", action="store_true",
+                    help="skip the host-delivered leg (profiling runs: its shorter launches would mix into the kernel statistics)")
     ap.add_argument("--settle", type=int, default=24,
                     help="at most this many extra untimed launches before the warm-up, ended as soon as the library has "
                          "settled the sweep kernel's cut of the iso range for the workload (it tries a few per workload)")
@@ -457,7 +459,7 @@ def main():
             out["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
         if wide:
             out["build_ms_gpu"] = build_ms  # the host builder and the CPU oracle cannot run at this size
-        if world == 1 and not wide and IN * W * H * 3 <= (1 << 30):
+        if world == 1 and not wide and not args.no_host_delivered and IN * W * H * 3 <= (1 << 30):
             # the sweep as the reference's caller gets it: frames in host memory (page-locked), src/main.zig:119-135
             try:
                 buf = r.pinned_frames(IN, H, W)
