@@ -33,9 +33,9 @@ stream = torch.cuda.Stream()
 
 def timed(call, reps):
     with torch.cuda.stream(stream):
-        for _ in range(2):
+        for _ in range(16):  # untimed, one by one: the library settles its cut of the iso range for this shard
             call()
-        stream.synchronize()
+            stream.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
             call()
