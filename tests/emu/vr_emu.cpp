@@ -277,7 +277,9 @@ extern "C" int vr_emu_wide(const uint32_t *nodes, uint64_t n_slots, const uint16
         for (uint32_t xi = 0; xi < width; xi++) {
             VrRay ray = vr_make_ray(k, xi, yi);
             HostPath path;
-            VrHit h = vr_trace_wide(k, ray, iso, HostWidePairs{ nodes, (uint32_t)(n_slots - 2u) }, path, pop_trips ? pop_trips : 64u, ahead_trips);
+            const HostWidePairs fetch{ nodes, (uint32_t)(n_slots - 2u) };
+            VrHit h = ahead_trips ? vr_trace_wide_ahead(k, ray, iso, fetch, path, pop_trips ? pop_trips : 64u, ahead_trips)
+                                  : vr_trace_wide(k, ray, iso, fetch, path, pop_trips ? pop_trips : 64u);
             uint64_t pix = (uint64_t)yi * width + xi;
             uint8_t g = h.flag == 1u ? vr_shade(h.t) : 0;
             rgb[pix * 3] = rgb[pix * 3 + 1] = rgb[pix * 3 + 2] = g;

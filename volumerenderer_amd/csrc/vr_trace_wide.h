@@ -221,9 +221,9 @@ VR_HD bool vr_wide_pop(VrWideLane &L, Path &path, uint32_t max_trips)
 }
 
 /* one whole ray */
-template <class NodeFetch, class Path>
-VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Path &path,
-                          uint32_t pop_trips = 64u, uint32_t ahead_trips = 0u)
+template <bool AHEAD, class NodeFetch, class Path>
+VR_HD VrHit vr_trace_wide_impl(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Path &path,
+                               uint32_t pop_trips, uint32_t ahead_trips)
 {
     VrHit h;
     h.t = 0.0f; h.flag = 2u; h.cell = 0; h.node = 0; h.checked = 0; h.moves = 0; h.escapes = 0; h.error = 0;
@@ -233,7 +233,7 @@ VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, Node
     h.flag = 0u;
     for (;;) {
         uint32_t go;
-        if (ahead_trips) { /* the bounded, reading-ahead descents of the persistent kernels */
+        if constexpr (AHEAD) { /* the bounded, reading-ahead descents of the persistent kernels */
             VrNoIsoTrack none;
             do go = vr_wide_descend_ahead(L, v, iso, fetch, path, ahead_trips, none); while (go == VR_GO_MORE);
         } else {
@@ -248,6 +248,21 @@ VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, Node
     h.t = L.t;
     h.checked = L.checked;
     return h;
+}
+
+template <class NodeFetch, class Path>
+VR_HD VrHit vr_trace_wide(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Path &path,
+                          uint32_t pop_trips = 64u)
+{
+    return vr_trace_wide_impl<false>(v, ray, iso, fetch, path, pop_trips, 0u);
+}
+
+/* the same ray with descents of at most ahead_trips levels that read both children ahead; fetch needs children() */
+template <class NodeFetch, class Path>
+VR_HD VrHit vr_trace_wide_ahead(const VrViewK &v, const VrRay &ray, uint32_t iso, NodeFetch fetch, Path &path,
+                                uint32_t pop_trips, uint32_t ahead_trips)
+{
+    return vr_trace_wide_impl<true>(v, ray, iso, fetch, path, pop_trips, ahead_trips);
 }
 
 #endif /* VR_TRACE_WIDE_H */
