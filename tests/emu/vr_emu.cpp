@@ -5,6 +5,8 @@
  */
 #include <cstdint>
 #include <cstring>
+#include <vector>
+#include <algorithm>
 
 #include "../../volumerenderer_amd/csrc/vr_trace_core.h"
 
@@ -118,7 +120,8 @@ static uint64_t div_check(uint64_t samples, uint64_t seed, uint32_t n_offsets)
  * cell, checks, moves and escape helps so far, and `upper` as it stood.  `share` such states are kept, newest on top:
  * the older ones lie in the shared part, where they are the next walk's own.
  * `ahead` != 0: descents read both children of a node ahead of its test (vr_lane_descend_ahead).
- * counts_out: [0] walks, [1] node reads, [2] the walks that carried on from a kept state. */
+ * counts_out: [0] walks, [1] node reads, [2] the walks that carried on from a kept state, [3] returns to the root
+ * walked (MOVEs that stayed inside the volume), [4] distinct ones among them per ray (by the bits of t), summed over the rays. */
 namespace {
 struct CountingFetch {
     const uint32_t *nodes;
@@ -158,7 +161,8 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
     std::memset(sums, 0, (size_t)iso_count * 7 * sizeof(uint64_t));
     const uint64_t frame = (uint64_t)width * height;
     if (chunk == 0) chunk = iso_count;
-    uint64_t f_test = 0, n_resumed = 0, n_fresh = 0;
+    uint64_t f_test = 0, n_resumed = 0, n_fresh = 0, n_segments = 0, n_states = 0;
+    std::vector<uint32_t> seen; /* t bit patterns of the returns to the root of one ray, over all its walks */
     for (uint32_t yi = 0; yi < height; yi++)
         for (uint32_t xi = 0; xi < width; xi++) {
             const uint64_t pix = (uint64_t)yi * width + xi;
@@ -174,6 +178,7 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
             VrLane L;
             vr_lane_begin(L, st, k, ray.dx, ray.dy, ray.dz, ray.t);
             const uint32_t cell0 = L.cell;
+            seen.clear();
             for (uint32_t c0 = 0; c0 < iso_count; c0 += chunk) {
                 const uint32_t last = iso_begin + (c0 + chunk < iso_count ? c0 + chunk : iso_count) - 1u;
                 struct Kept { uint32_t cell, checked, moves, esc, upper; float t; };
@@ -210,6 +215,8 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
                         const uint32_t at_move = L.checked;
                         if (!vr_lane_move(L, k, esc)) break;
                         seg = Kept{ L.cell, at_move, moves, esc, track.upper, L.t };
+                        n_segments++;
+                        { uint32_t tb; std::memcpy(&tb, &L.t, 4); seen.push_back(tb); }
                         while (!vr_lane_pop(L, st, max_trips)) {}
                     }
                     const uint32_t e = track.upper < last ? track.upper : last;
@@ -226,8 +233,10 @@ extern "C" int vr_emu_sweep(const uint32_t *nodes, uint64_t n_slots, const uint8
                     iso = e + 1u;
                 }
             }
+            std::sort(seen.begin(), seen.end());
+            n_states += (uint64_t)(std::unique(seen.begin(), seen.end()) - seen.begin());
         }
-    if (counts_out) { counts_out[0] = n_resumed + n_fresh; counts_out[1] = f_test; counts_out[2] = n_resumed; }
+    if (counts_out) { counts_out[0] = n_resumed + n_fresh; counts_out[1] = f_test; counts_out[2] = n_resumed; counts_out[3] = n_segments; counts_out[4] = n_states; }
     return 0;
 }
 
@@ -312,4 +321,133 @@ extern "C" void vr_emu_trilerp(const float *in, uint64_t n, float *out)
 extern "C" void vr_emu_corner_dens(const uint8_t *vox, uint32_t ry, uint32_t rz, uint32_t cx, uint32_t cy, uint32_t cz, float out[8])
 {
     vr_corner_dens(vox, ry, rz, cx, cy, cz, out);
+}
+
+/* ---- the union walk (vr_trace_union.h): ONE traversal per ray for a whole range of iso values ---- */
+#include "../../volumerenderer_amd/csrc/vr_trace_union.h"
+namespace {
+struct HostDone {
+    uint32_t w[8];
+    uint32_t word(uint32_t i) const { return w[i]; }
+    void set(uint32_t i, uint32_t bits) { w[i] |= bits; }
+    void clear(uint32_t i) { w[i] = 0u; }
+};
+struct HostUnionSink {
+    const VrViewK *k; const uint32_t *nodes; const VrLane *ray; /* for iso values that are walked on their own */
+    uint32_t iso_begin; uint64_t frame, pix;
+    uint8_t *gray; uint32_t *cell_flag; float *t_out; uint32_t *node; uint64_t *sums;
+    uint64_t n_except = 0, n_except_isos = 0;
+    void finish(uint32_t iso, bool hit, float t, uint32_t cell, uint32_t g)
+    {
+        const uint64_t at = (uint64_t)(iso - iso_begin) * frame + pix;
+        gray[at] = hit ? vr_shade(t) : 0;
+        cell_flag[at] = (hit ? vr_unpack_cell(cell) : 0u) | ((hit ? 1u : 0u) << 24);
+        t_out[at] = t;
+        node[at] = hit ? g - 1u : 0u;
+        sums[(iso - iso_begin) * 7 + (hit ? 1 : 2)]++;
+    }
+    void park(uint32_t r0, uint32_t r1, uint32_t checks)
+    {
+        for (uint32_t i = r0; i <= r1; i++) { sums[(i - iso_begin) * 7 + 0] += checks; sums[(i - iso_begin) * 7 + 5] += 1u; }
+    }
+    void hit(uint32_t r0, uint32_t r1, uint32_t checks, float t, uint32_t cell, uint32_t g)
+    {
+        for (uint32_t i = r0; i <= r1; i++) { sums[(i - iso_begin) * 7 + 0] += checks; finish(i, true, t, cell, g); }
+    }
+    void miss(uint32_t r0, uint32_t r1, float t) { for (uint32_t i = r0; i <= r1; i++) finish(i, false, t, 0, 0); }
+    void esc(uint32_t r0, uint32_t r1, uint32_t n) { for (uint32_t i = r0; i <= r1; i++) sums[(i - iso_begin) * 7 + 4] += n; }
+    /* iso values whose own MOVE lands elsewhere: each walked on its own from its own state (the checks and the MOVE
+     * of the round that parked them are counted already) */
+    void except(uint32_t r0, uint32_t r1, float t, uint32_t cell, bool in_root, uint32_t n_esc)
+    {
+        n_except++;
+        for (uint32_t iso = r0; iso <= r1; iso++) {
+            n_except_isos++;
+            sums[(iso - iso_begin) * 7 + 4] += n_esc;
+            if (!in_root) { finish(iso, false, t, 0, 0); continue; }
+            HostStack st;
+            VrLane A = *ray;
+            vr_lane_restart(A, st, *k, t, cell);
+            uint32_t moves = 0, e = 0;
+            bool hit = false;
+            for (;;) {
+                const uint32_t go = vr_lane_descend(A, iso, HostFetch{ nodes }, st, 64u);
+                if (go == VR_GO_HIT) { hit = true; break; }
+                moves++;
+                if (!vr_lane_move(A, *k, e)) break;
+                while (!vr_lane_pop(A, st, 64u)) {}
+            }
+            sums[(iso - iso_begin) * 7 + 0] += A.checked; sums[(iso - iso_begin) * 7 + 4] += e; sums[(iso - iso_begin) * 7 + 5] += moves;
+            finish(iso, hit, A.t, A.cell, A.g);
+        }
+    }
+};
+} // namespace
+
+/* counts_out: [0] node reads of the descents, [1] states (MOVEs of the front), [2] suspect MOVEs resolved exactly,
+ * [3] runs of iso values that left the union walk, [4] iso values in them */
+extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], const float src[3],
+                            const float forw[3], const float up[3], uint32_t width, uint32_t height, float viewport_width,
+                            uint32_t iso_begin, uint32_t iso_count, uint32_t max_trips, uint8_t *gray, uint32_t *cell_flag,
+                            float *t_out, uint32_t *node, uint64_t *sums /*[iso_count][7]*/, uint64_t *counts_out /*[5]*/)
+{
+    VrViewK k;
+    k.ox = src[0]; k.oy = src[1]; k.oz = src[2];
+    k.fx = forw[0]; k.fy = forw[1]; k.fz = forw[2];
+    k.ux = up[0]; k.uy = up[1]; k.uz = up[2];
+    k.rx = k.fy * k.uz - k.fz * k.uy;
+    k.ry = k.fz * k.ux - k.fx * k.uz;
+    k.rz = k.fx * k.uy - k.fy * k.ux;
+    k.pixel_size = viewport_width / (float)width;
+    k.half_w = (float)(width / 2);
+    k.half_h = (float)(height / 2);
+    k.width = width; k.height = height;
+    k.rdx = root_dim[0]; k.rdy = root_dim[1]; k.rdz = root_dim[2];
+    k.root_hi = vr_pack10(k.rdx, k.rdy, k.rdz);
+    k.n_slots = n_slots;
+    std::memset(sums, 0, (size_t)iso_count * 7 * sizeof(uint64_t));
+    const uint64_t frame = (uint64_t)width * height;
+    uint64_t n_reads = 0, n_states = 0, n_suspect = 0, n_except = 0, n_except_isos = 0;
+    for (uint32_t yi = 0; yi < height; yi++)
+        for (uint32_t xi = 0; xi < width; xi++) {
+            const uint64_t pix = (uint64_t)yi * width + xi;
+            VrRay ray = vr_make_ray(k, xi, yi);
+            if (ray.oob) {
+                for (uint32_t j = 0; j < iso_count; j++) {
+                    gray[j * frame + pix] = 0; cell_flag[j * frame + pix] = 2u << 24; t_out[j * frame + pix] = 0.0f;
+                    node[j * frame + pix] = 0; sums[j * 7 + 3]++;
+                }
+                continue;
+            }
+            HostStack st;
+            HostDone done;
+            VrUnionLane U;
+            vr_union_begin(U, st, done, k, ray.dx, ray.dy, ray.dz, ray.t, iso_begin, iso_count);
+            const VrLane ray_lane = U.L;
+            HostUnionSink sink{ &k, nodes, &ray_lane, iso_begin, frame, pix, gray, cell_flag, t_out, node, sums };
+            const CountingFetch fetch{ nodes, &n_reads, (uint32_t)(n_slots - 1u) & ~1u };
+            while (U.alive_lo <= U.alive_hi) {
+                const uint32_t go = vr_union_descend(U, fetch, st, done, sink, max_trips);
+                if (go == VR_GO_MORE) continue;
+                if (U.alive_lo > U.alive_hi) break;
+                n_states++;
+                const uint32_t depth_k = st.depth(), cell_before = U.L.cell;
+                const VrUnionExit x = vr_union_move(U.L, k);
+                bool suspect = x.esc != 0u;
+                if (!x.in_root) {
+                    const float t_new = U.L.t;
+                    vr_union_leave(U.L, st, x, suspect);
+                    if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false); }
+                    if (U.alive_lo <= U.alive_hi)
+                        vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1, t_new); });
+                    break;
+                }
+                while (!vr_union_pop(U.L, st, max_trips, x, suspect)) {}
+                if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, (int)st.depth() - 1, U.L.t, U.L.cell, true); }
+                vr_union_after_pop(U, HostFetch{ nodes });
+            }
+            n_except += sink.n_except; n_except_isos += sink.n_except_isos;
+        }
+    if (counts_out) { counts_out[0] = n_reads; counts_out[1] = n_states; counts_out[2] = n_suspect; counts_out[3] = n_except; counts_out[4] = n_except_isos; }
+    return 0;
 }

@@ -69,7 +69,7 @@ def emu_sweep(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, chunk=0, 
     ck = np.zeros((iso_count, h, w), np.uint32)
     nd = np.zeros((iso_count, h, w), np.uint32)
     sums = np.zeros((iso_count, 7), np.uint64)
-    counts = np.zeros(3, np.uint64)
+    counts = np.zeros(5, np.uint64)
     f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
     prep = np.ascontiguousarray(prep, dtype=np.uint32)
     L.vr_emu_sweep(C.c_void_p(prep.ctypes.data), C.c_uint64(n_slots), (C.c_uint8 * 3)(*[int(x) for x in rd]), f3(pos),
@@ -78,7 +78,29 @@ def emu_sweep(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, chunk=0, 
                    C.c_void_p(cf.ctypes.data), C.c_void_p(tt.ctypes.data), C.c_void_p(ck.ctypes.data),
                    C.c_void_p(nd.ctypes.data), C.c_void_p(sums.ctypes.data), C.c_void_p(counts.ctypes.data))
     return {"gray": gray, "cell_flag": cf, "t": tt, "checked": ck, "node": nd, "sums": sums, "traces": int(counts[0]),
-            "node_reads": int(counts[1]), "carried_on": int(counts[2])}
+            "node_reads": int(counts[1]), "carried_on": int(counts[2]), "returns_walked": int(counts[3]),
+            "returns_distinct": int(counts[4])}
+
+
+def emu_union(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, max_trips=5):
+    """The sweep as ONE traversal per ray for all iso values (vr_trace_union.h), on the CPU (tests/emu/vr_emu.cpp)."""
+    n_slots = len(nodes)
+    rc, prep, _, _ = prepare_nodes(nodes, rd)
+    assert rc == 0
+    gray = np.zeros((iso_count, h, w), np.uint8)
+    cf = np.zeros((iso_count, h, w), np.uint32)
+    tt = np.zeros((iso_count, h, w), np.float32)
+    nd = np.zeros((iso_count, h, w), np.uint32)
+    sums = np.zeros((iso_count, 7), np.uint64)
+    counts = np.zeros(5, np.uint64)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+    prep = np.ascontiguousarray(prep, dtype=np.uint32)
+    L.vr_emu_union(C.c_void_p(prep.ctypes.data), C.c_uint64(n_slots), (C.c_uint8 * 3)(*[int(x) for x in rd]), f3(pos),
+                   f3(f), f3(u), C.c_uint32(w), C.c_uint32(h), C.c_float(vp), C.c_uint32(iso_begin), C.c_uint32(iso_count),
+                   C.c_uint32(max_trips), C.c_void_p(gray.ctypes.data), C.c_void_p(cf.ctypes.data), C.c_void_p(tt.ctypes.data),
+                   C.c_void_p(nd.ctypes.data), C.c_void_p(sums.ctypes.data), C.c_void_p(counts.ctypes.data))
+    return {"gray": gray, "cell_flag": cf, "t": tt, "node": nd, "sums": sums, "node_reads": int(counts[0]),
+            "states": int(counts[1]), "suspect": int(counts[2]), "left_runs": int(counts[3]), "left_isos": int(counts[4])}
 
 
 def assert_same_render(got, ref, what=""):

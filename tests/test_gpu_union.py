@@ -1,0 +1,119 @@
+"""GPU parity of the kernel with ONE traversal per ray for a whole range of iso values (vr_k_union) through the C ABI:
+frames and per-iso counters against the oracle's separate render of each iso value, and against the kernels with one
+traversal per iso value / shared traversals at full size.  (Per-pixel taps are served by the other kernels: the
+reference-defined check count of a pixel needs that iso value's own walk.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import volumerenderer_amd as vr
+from volumerenderer_amd import capi
+from test_gpu_parity import c60_renderer, skull_renderer, standin_tree, standin_renderer, _check_stats  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def test_union_kernel_every_iso_value_matches_oracle(oracle, c60_vox, c60_tree, c60_renderer, skull_vox, skull_tree,
+                                                     skull_renderer):
+    """All 256 iso values on C60, a block on Skull, ranges that do not start at 0 or end at 255, a single iso value:
+    pixels and all counters of every iso value equal the oracle's render of that iso value."""
+    for vox, tree, rnd, W, H, b, n in [(c60_vox, c60_tree, c60_renderer, 96, 80, 0, 256),
+                                       (skull_vox, skull_tree, skull_renderer, 160, 128, 60, 40),
+                                       (c60_vox, c60_tree, c60_renderer, 33, 47, 251, 5),
+                                       (c60_vox, c60_tree, c60_renderer, 64, 64, 100, 1),
+                                       (skull_vox, skull_tree, skull_renderer, 200, 160, 0, 256)]:
+        nodes, rd, _ = tree
+        pos, forw, up = oracle.main_camera(vox.shape)
+        rnd.set_kernel(capi.KERNEL_UNION)
+        out = rnd.renderSweep(pos, forw, up, W, H, 2.0, b, n)
+        rnd.set_kernel(capi.KERNEL_DEFAULT)
+        for j in range(0, n, 1 if W * H < 10000 else 3):
+            ref = oracle.render(nodes, rd, pos, forw, up, W, H, 2.0, b + j)
+            assert (out["rgb"][j] == ref["rgb"]).all(), "union kernel iso %d: %d pixels differ" % (b + j, int((out["rgb"][j] != ref["rgb"]).sum()))
+            _check_stats({"stats": out["stats"][j]}, ref)
+
+
+def test_union_kernel_equals_per_iso_kernel_at_full_size(oracle, skull_vox, skull_renderer):
+    """Skull 1024^2, all 256 iso values: frames and all 7 counters of the union kernel and of the one-traversal-per-iso
+    kernel are identical; the default picks the union kernel."""
+    import torch
+    pos, forw, up = oracle.main_camera(skull_vox.shape)
+    L = capi.lib()
+    W = H = 1024
+    v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+    res = []
+    for variant in (capi.KERNEL_PIPELINE, capi.KERNEL_UNION, capi.KERNEL_DEFAULT):
+        skull_renderer.set_kernel(variant)
+        d_rgb = torch.empty((256, H, W, 3), dtype=torch.uint8, device="cuda")
+        d_stats = torch.zeros((256, 7), dtype=torch.int64, device="cuda")
+        capi.check(L.vr_render_device(skull_renderer.handle, C.byref(v), 0, 256, 0, H, d_rgb.data_ptr(), d_stats.data_ptr(),
+                                      None, None), "vr_render_device")
+        capi.check(L.vr_sync(skull_renderer.handle), "vr_sync")
+        res.append((d_rgb, d_stats.cpu().numpy()))
+    skull_renderer.set_kernel(capi.KERNEL_DEFAULT)
+    for k in (1, 2):
+        assert (res[0][1] == res[k][1]).all(), np.argwhere(res[0][1] != res[k][1])[:8]
+        assert bool(torch.equal(res[0][0], res[k][0]))
+    assert int(res[0][1][:, 0].sum()) == 8519971365 and int(res[0][1][:, 6].sum()) == 0
+    si = capi.SweepInfo()
+    capi.check(L.vr_sweep_info_read(skull_renderer.handle, C.byref(si)), "vr_sweep_info_read")
+    assert si.walks == si.items and si.walks >= 250000  # one traversal per entering ray and block of iso values
+
+
+def test_union_kernel_on_the_256_cubed_volume_at_full_size(oracle, standin_tree, standin_renderer):
+    """The 256^3 stand-in (depth-24 tree) at 1024^2, iso 0..255: the union kernel equals the kernel with traversals
+    shared between iso values, frames and counters; so do two row ranges and a band shard rendered on their own."""
+    import torch
+    from volumerenderer_amd import sharding
+    vox, _ = standin_tree
+    pos, forw, up = oracle.main_camera(vox.shape)
+    L = capi.lib()
+    W = H = 1024
+    v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+
+    def run(variant, r0=0, r1=H):
+        standin_renderer.set_kernel(variant)
+        d_rgb = torch.empty((256, r1 - r0, W, 3), dtype=torch.uint8, device="cuda")
+        d_stats = torch.zeros((256, 7), dtype=torch.int64, device="cuda")
+        capi.check(L.vr_render_device(standin_renderer.handle, C.byref(v), 0, 256, r0, r1, d_rgb.data_ptr(), d_stats.data_ptr(),
+                                      None, None), "vr_render_device")
+        capi.check(L.vr_sync(standin_renderer.handle), "vr_sync")
+        standin_renderer.set_kernel(capi.KERNEL_DEFAULT)
+        return d_rgb, d_stats.cpu().numpy()
+
+    sweep = run(capi.KERNEL_SWEEP)
+    union = run(capi.KERNEL_UNION)
+    assert (sweep[1] == union[1]).all() and int(union[1][:, 6].sum()) == 0 and int(union[1][:, 1].sum()) > 10 ** 7
+    assert bool(torch.equal(sweep[0], union[0]))
+    part = run(capi.KERNEL_UNION, 300, 555)
+    assert bool(torch.equal(part[0], union[0][:, 300:555]))
+    sh = sharding.band_shard(3, 8, H)
+    standin_renderer.set_kernel(capi.KERNEL_UNION)
+    d_rgb = torch.empty((256, sh["n_rows"], W, 3), dtype=torch.uint8, device="cuda")
+    capi.check(L.vr_render_device_bands(standin_renderer.handle, C.byref(v), 0, 256, sh["row_begin"], sh["band_rows"], sh["band_pitch"],
+                                        sh["n_bands"], d_rgb.data_ptr(), None, None, None), "vr_render_device_bands")
+    capi.check(L.vr_sync(standin_renderer.handle), "vr_sync")
+    standin_renderer.set_kernel(capi.KERNEL_DEFAULT)
+    rows = torch.tensor(sharding.band_rows_of(3, 8, H), device="cuda")
+    assert bool(torch.equal(d_rgb, union[0][:, rows]))
+
+
+def test_union_kernel_with_no_ray_entering_the_volume_and_with_taps(oracle, c60_vox, c60_tree, c60_renderer):
+    """A camera that looks away from the volume: every frame black, every ray OOB, nothing hangs.  With taps asked for the
+    call is served by the kernel that walks per iso value (the taps stay exact)."""
+    pos = np.array([-30.0, -300.0, -30.0], np.float32)
+    forw = np.array([0.0, -1.0, 0.0], np.float32)
+    up = np.array([0.0, 0.0, 1.0], np.float32)
+    c60_renderer.set_kernel(capi.KERNEL_UNION)
+    out = c60_renderer.renderSweep(pos, forw, up, 70, 50, 2.0, 0, 256)
+    assert not out["rgb"].any()
+    assert all(s["oob_count"] == 70 * 50 and s["nodes_checked"] == 0 and s["hit_count"] == 0 for s in out["stats"])
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    out = c60_renderer.renderSweep(pos, forw, up, 40, 40, 2.0, 90, 12, taps=True)
+    c60_renderer.set_kernel(capi.KERNEL_DEFAULT)
+    for j in range(12):
+        ref = oracle.render(nodes, rd, pos, forw, up, 40, 40, 2.0, 90 + j)
+        assert (out["rgb"][j] == ref["rgb"]).all() and (out["checked"][j] == ref["checked"]).all()
+        assert (out["t"][j].view(np.uint32) == ref["t"].view(np.uint32)).all()

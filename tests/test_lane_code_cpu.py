@@ -114,3 +114,45 @@ def test_shared_traversals_on_noise_and_partial_ranges(oracle, emu_lib):
             ref = oracle.render(nodes, rd, pos, forw, up, 24, 16, 0.15, b + j)
             assert (got["gray"][j] == ref["rgb"][..., 0]).all() and (got["checked"][j] == ref["checked"]).all(), (b, j)
             assert (got["t"][j].view(np.uint32) == ref["t"].view(np.uint32)).all(), (b, j)
+
+
+def _check_union(oracle, got, nodes, rd, pos, forw, up, W, H, vp, b, n, step=1):
+    for j in range(0, n, step):
+        ref = oracle.render(nodes, rd, pos, forw, up, W, H, vp, b + j)
+        hit = (ref["cell_flag"] >> 24) == 1
+        assert (got["gray"][j] == ref["rgb"][..., 0]).all(), (b, j)
+        assert (got["cell_flag"][j] == ref["cell_flag"]).all() and (got["node"][j] == ref["node"]).all(), (b, j)
+        assert (got["t"][j].view(np.uint32)[hit] == ref["t"].view(np.uint32)[hit]).all(), (b, j)
+        st = ref["stats"]
+        assert tuple(int(x) for x in got["sums"][j][:6]) == (st.nodes_checked, st.hit_count, st.miss_count, st.oob_count,
+                                                             st.escape_help_events, st.moves), (b, j)
+
+
+@pytest.mark.parametrize("trips", [5, 1, 64])
+def test_union_walk_equals_one_render_per_iso(oracle, emu_lib, c60_vox, c60_tree, trips):
+    """ONE traversal per ray for all 256 iso values (the front goes wherever an iso value that is not done holds;
+    excluded iso values wait where the front leaves the excluding node's box): pixels, hit cells, t bits of the hits, hit
+    leaves and every per-iso counter equal the oracle's separate render of each iso value; the few iso values whose own
+    MOVE parts from the front's are found and walked on their own."""
+    from helpers import emu_union, emu_sweep
+    nodes, rd, _ = c60_tree
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    W = H = 48
+    got = emu_union(emu_lib, nodes, rd, pos, forw, up, W, H, 2.0, 0, 256, max_trips=trips)
+    _check_union(oracle, got, nodes, rd, pos, forw, up, W, H, 2.0, 0, 256)
+    shared = emu_sweep(emu_lib, nodes, rd, pos, forw, up, W, H, 2.0, 0, 256, max_trips=5, share=2)
+    assert got["node_reads"] * 4 < shared["node_reads"]  # far fewer node reads than walks shared between iso values
+    assert got["left_isos"] * 50 < 256 * W * H           # and leaving the union walk is rare
+
+
+def test_union_walk_on_noise_partial_ranges_and_close_cameras(oracle, emu_lib):
+    from helpers import emu_union
+    rng = np.random.default_rng(11)
+    for shape, kind, heur in [((9, 12, 7), "noise", "AlwaysCenter"), ((16, 16, 16), "smooth", None), ((12, 9, 14), "sparse", "AlwaysCenter")]:
+        vox = random_volume(rng, shape, kind)
+        nodes, rd, _ = oracle.build_kdt(vox, heur) if heur else oracle.build_kdt(vox)
+        for cam, vp in [((50.0, -120.0, 30.0), 0.15), ((-30.0, -300.0, -30.0), 0.2), ((4.0, 5.0, -60.0), 0.5)]:
+            pos, forw, up = oracle.main_camera(vox.shape, cam)
+            for b, n in [(0, 256), (17, 100), (255, 1), (200, 56)]:
+                got = emu_union(emu_lib, nodes, rd, pos, forw, up, 24, 16, vp, b, n, max_trips=3)
+                _check_union(oracle, got, nodes, rd, pos, forw, up, 24, 16, vp, b, n, step=1 if n <= 100 else 3)

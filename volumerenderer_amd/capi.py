@@ -18,6 +18,7 @@ FLAG_MISS, FLAG_HIT, FLAG_OOB = 0, 1, 2
 
 SHARD_ISO, SHARD_ROWS = 0, 1
 KERNEL_DEFAULT, KERNEL_RESTART_GLOBAL, KERNEL_RESTART_LDS, KERNEL_RESUME, KERNEL_PIPELINE, KERNEL_SWEEP = 0, 1, 2, 3, 4, 5
+KERNEL_UNION = 6  # one traversal per ray for the whole iso range
 
 HEURISTICS = {
     "AlwaysCenter": 0,

@@ -47,7 +47,8 @@ struct vr_ctx {
     size_t stats_cap = 0;
     void *d_tap[4] = { nullptr, nullptr, nullptr, nullptr };
     size_t tap_cap[4] = { 0, 0, 0, 0 };
-    uint32_t last_ipl = 0; /* items per lane of the last sweep-kernel launch */
+    uint32_t last_ipl = 0; /* items per lane of the last sweep-kernel launch (0: one traversal per ray, nothing to cut) */
+    bool ranges_nested = true; /* node ranges nested along every path: built trees always, uploaded ones when checked so */
     size_t info_off = 0; /* where the last sweep-kernel launch in d_work left its report; 0 = none yet */
     /* The sweep kernel's cut of the iso range, tuned per workload from its own reports.  Every sweep launch in the
      * context's scratch is tagged with a sequence number and followed by an asynchronous copy of its report into
@@ -252,6 +253,7 @@ int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint
     if (!prepared) return VR_ENOMEM;
     int rc = vr_host_prepare_kdt(nodes, n_slots, root_dim, prepared, prep_words, &max_depth, nullptr);
     if (rc != VR_OK) { std::free(prepared); return rc; }
+    const bool nested = vr_host_ranges_nested(prepared, prep_words);
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
     free_prepared(c);
@@ -267,6 +269,7 @@ int vr_upload_kdt(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const uint
     c->max_depth = max_depth;
     c->root_dim[0] = root_dim[0]; c->root_dim[1] = root_dim[1]; c->root_dim[2] = root_dim[2];
     c->wide = false;
+    c->ranges_nested = nested;
     return VR_OK;
 }
 
@@ -347,6 +350,7 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
         c->max_depth = depth;
         for (int a = 0; a < 3; a++) c->root_dim[a] = c->res[a] - 1u;
         c->wide = false;
+        c->ranges_nested = true; /* a node's range is the union of its children's */
         return VR_OK;
     }
     /* centre split: built on the device, valid by construction (no host walk, no PCIe traffic) */
@@ -366,6 +370,7 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
     c->max_depth = depth;
     for (int a = 0; a < 3; a++) c->root_dim[a] = c->res[a] - 1u;
     c->wide = false;
+    c->ranges_nested = true; /* a node's range is the union of its children's */
     if (stats_out) {
         /* a full binary tree over the cells: 2 * cells - 1 nodes; every partition is the centre one */
         const uint64_t cells = (uint64_t)(c->res[0] - 1u) * (c->res[1] - 1u) * (c->res[2] - 1u);
@@ -410,32 +415,36 @@ int vr_download_kdt_wide(vr_ctx *c, uint32_t *nodes_out, uint64_t first_slot, ui
 /* Picks the sweep kernel's items-per-lane for this launch and tags it (see vr_ctx::SweepTune). */
 static constexpr int kSweepSamples = 3;
 /* where the search starts: short sweeps have few distinct walks per ray to share, and every cut costs one more */
-static uint32_t sweep_cut_base(uint32_t iso_count)
+static uint32_t sweep_cut_base(uint32_t iso_count, bool union_kernel = false)
 {
+    if (union_kernel) { /* one traversal per ray and block: blocks only shorten the longest walk and fill the lanes */
+        const uint32_t b = iso_count / 64u;
+        return b < 1u ? 1u : (b > VR_UNION_ITEMS_DEFAULT ? VR_UNION_ITEMS_DEFAULT : b);
+    }
     const uint32_t b = iso_count / 8u;
     return b < 2u ? 2u : (b > VR_SWEEP_ITEMS_DEFAULT ? VR_SWEEP_ITEMS_DEFAULT : b);
 }
-/* the step-th candidate below (dir < 0: 3/4, 1/2, 1/4 of the base) or above it (11/8, 2x); 0 = none left */
+/* the step-th candidate below (dir < 0: 3/4, 1/2, 1/4 of the base) or above it (3/2, 2x, 4x); 0 = none left */
 static uint32_t sweep_cut_candidate(uint32_t base, int dir, int step)
 {
-    static const uint32_t num[2][3] = { { 6u, 4u, 2u }, { 11u, 16u, 0u } };
+    static const uint32_t num[2][3] = { { 6u, 4u, 2u }, { 12u, 16u, 32u } };
     if (step > 2 || num[dir < 0 ? 0 : 1][step] == 0u) return 0u;
     const uint32_t c = (base * num[dir < 0 ? 0 : 1][step] + 4u) / 8u;
     const uint32_t prev = step == 0 ? base : (base * num[dir < 0 ? 0 : 1][step - 1] + 4u) / 8u;
     return c == prev || c == 0u ? 0u : c;
 }
 static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
-                            uint32_t n_rows, uint32_t band_rows, uint32_t *ipl_out, uint32_t *seq_out)
+                            uint32_t n_rows, uint32_t band_rows, bool union_kernel, uint32_t *ipl_out, uint32_t *seq_out)
 {
     static const bool tune_debug = std::getenv("VR_TUNE_DEBUG") != nullptr; /* VR_TUNE_DEBUG=1: the decisions, on stderr */
     vr_ctx::SweepTune &t = c->tune;
     uint64_t key = 1469598103934665603ull; /* FNV-1a over what defines the workload's shape (not the camera) */
-    const uint64_t parts[] = { c->tree_id, view->width, view->height, row_begin, n_rows, band_rows, iso_begin, iso_count };
+    const uint64_t parts[] = { c->tree_id, view->width, view->height, row_begin, n_rows, band_rows, iso_begin, iso_count, union_kernel };
     for (uint64_t p : parts) { key ^= p; key *= 1099511628211ull; }
     if (key != t.key) {
         t = vr_ctx::SweepTune();
         t.key = key;
-        t.base = t.best_ipl = sweep_cut_base(iso_count);
+        t.base = t.best_ipl = sweep_cut_base(iso_count, union_kernel);
         c->h_info[5] = 0; /* a report of the previous workload must not be taken for one of this */
     }
     /* the newest report that has arrived */
@@ -538,19 +547,26 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         ev0 = c->ev[c->ev_used];
         ev1 = c->ev[c->ev_used + 1];
     }
-    const bool sweep_kernel = variant == VR_KERNEL_SWEEP || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u);
-    uint32_t ipl = sweep_cut_base(iso_count), seq = 0; /* the no-allocation entry point stays on this */
+    const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
+    /* one traversal per ray for the whole iso range: nothing to cut, nothing to tune (same rule as vr_launch_render) */
+    const bool union_kernel = !c->wide && c->ranges_nested && !any_tap &&
+                              (variant == VR_KERNEL_UNION || (variant == VR_KERNEL_DEFAULT && iso_count >= VR_UNION_MIN_ISOS));
+    const bool sweep_kernel = !union_kernel && (variant == VR_KERNEL_SWEEP || variant == VR_KERNEL_UNION ||
+                                                (variant == VR_KERNEL_DEFAULT && iso_count >= 8u));
+    uint32_t ipl = sweep_cut_base(iso_count, union_kernel), seq = 0; /* the no-allocation entry point stays on this */
     static const uint32_t forced_ipl = std::getenv("VR_SWEEP_ITEMS") ? (uint32_t)std::atoi(std::getenv("VR_SWEEP_ITEMS")) : 0u; /* for tuning runs */
     if (forced_ipl) ipl = forced_ipl;
-    else if (sweep_kernel && !fixed_scratch) sweep_tune_next(c, view, iso_begin, iso_count, row_begin, row_end - row_begin, band_rows, &ipl, &seq);
+    else if ((sweep_kernel || union_kernel) && !fixed_scratch)
+        sweep_tune_next(c, view, iso_begin, iso_count, row_begin, row_end - row_begin, band_rows, union_kernel, &ipl, &seq);
     if (c->wide)
         VR_HIP(vr_launch_render_wide(variant, s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
                                      (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq));
     else
         VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
-                                row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq));
+                                row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq,
+                                c->ranges_nested));
     if (timing) c->ev_used += 2;
-    if (sweep_kernel && !fixed_scratch) {
+    if ((sweep_kernel || union_kernel) && !fixed_scratch) {
         c->info_off = vr_pipeline_info_offset(view->width, row_end - row_begin);
         c->last_ipl = ipl;
         if (c->tune.phase != 2 && !forced_ipl) /* the report follows the launch on its stream; the next launch reads it if it has arrived */
@@ -887,6 +903,7 @@ const char *vr_kernel_name(int variant)
     case VR_KERNEL_RESUME: return "resume";
     case VR_KERNEL_PIPELINE: return "pipeline";
     case VR_KERNEL_SWEEP: return "sweep";
+    case VR_KERNEL_UNION: return "union";
     default: return nullptr;
     }
 }

@@ -425,6 +425,20 @@ int vr_host_prepare_kdt(const uint32_t *nodes, uint64_t n_slots, const uint8_t r
     return VR_OK;
 }
 
+/* Are the density ranges nested along every path of a prepared tree (every reachable node's range inside its
+ * parent's)?  True for every tree built from a volume -- a node's range is the union of its children's -- and what the
+ * kernel with one traversal per ray for all iso values relies on.  Words of unreachable slots are 0 and skipped
+ * (a reachable node's word is never 0: a leaf has bit 31 set, an inner node a partition above its box's lower bound). */
+bool vr_host_ranges_nested(const uint32_t *prepared, uint64_t prepared_words)
+{
+    for (uint64_t g = 2; g < prepared_words; g++) {
+        const uint32_t n = prepared[g], p = prepared[g >> 1];
+        if (n == 0u || p == 0u) continue;
+        if ((n & 0xffu) < (p & 0xffu) || ((n >> 8) & 0xffu) > ((p >> 8) & 0xffu)) return false;
+    }
+    return true;
+}
+
 int vr_host_check_kdt_wide(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3], uint32_t *max_depth_out,
                            uint64_t *n_nodes_out)
 {

@@ -25,13 +25,24 @@ enum {
                                   /* traversal per ray and iso value (default for fewer than 8 iso values)  */
     VR_KERNEL_SWEEP = 5,          /* the same machinery with traversals shared between iso values      */
                                   /* (default from 8 iso values on)                                   */
-    VR_KERNEL_COUNT = 6
+    VR_KERNEL_UNION = 6,          /* one traversal per ray for the whole iso range (falls back to the sweep */
+                                  /* kernel with taps or node ranges that are not nested)                   */
+    VR_KERNEL_COUNT = 7
 };
 
 /* The sweep kernel cuts the iso range into as many blocks as it takes to have this many (ray, iso block) items per
  * lane of the grid: more blocks balance better, and every block re-walks its first traversal.  launch_seq tags the
  * launch in the kernel's report (0 = untagged). */
 #define VR_SWEEP_ITEMS_DEFAULT 8u
+/* (ray, iso block) items per lane of the grid that the union kernel starts from for long sweeps (tuned per workload) */
+#define VR_UNION_ITEMS_DEFAULT 4u
+/* iso values per call from which the default is the kernel with one traversal per ray for all of them */
+#define VR_UNION_MIN_ISOS 8u
+/* runs of iso values that may leave the union walks of one call (a few per thousand rays do) */
+#define VR_UNION_EXCEPT_CAP 32768u
+
+/* Are the density ranges of a prepared tree nested along every path (vr_host.cpp)? */
+extern "C" bool vr_host_ranges_nested(const uint32_t *prepared, uint64_t prepared_words);
 
 /* Device scratch the pipeline variant needs for one call (ray list, tile offsets, queue heads). */
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count);
@@ -46,7 +57,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                             const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
                             const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end,
-                            uint32_t sweep_items_per_lane, uint32_t launch_seq);
+                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested);
 
 /* Once per device, with that device current (vr_ctx_create calls it; safe from several threads): raises the
  * dynamic-LDS ceiling of the persistent kernels, which is a property of the function on the device, and looks

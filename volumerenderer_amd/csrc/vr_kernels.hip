@@ -31,6 +31,7 @@
 
 #include "vr_internal.h"
 #include "vr_trace_wide.h"
+#include "vr_trace_union.h"
 
 namespace {
 
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, 
         /* the sweep kernel's report (vr_sweep_info, 64 bytes behind the ray count): walks, items, first / queue-empty / last tick */
         unsigned long long *info = (unsigned long long *)(n_active_out + 16);
         info[0] = 0; info[1] = 0; info[2] = ~0ull; info[3] = ~0ull; info[4] = 0; info[5] = 0;
+        n_active_out[32] = 0u; /* the union kernel's count of iso runs that left the union walk (128 bytes behind the ray count) */
     }
     /* the small set-up work of a call rides along: empty queues, and the per-iso counters at their starting
      * values (every pixel that never enters the volume is OOB in every frame) */
@@ -983,12 +985,21 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
         if (exhausted) { d_acc[10] += 1; d_acc[11] += __popcll(__ballot(alive)); }
 #endif
 
+#ifdef VR_DIAG
+        const unsigned long long d_p0 = __builtin_amdgcn_s_memtime();
+        unsigned long long d_p1 = d_p0, d_p2 = d_p0, d_p3 = d_p0;
+        d_acc[2] += __popcll(__ballot(alive && !popping));
+#endif
         if (alive) {
             uint32_t go = VR_GO_MORE;
             /* ---- descend while the node's density range holds the iso value (bounded) ---- */
             if (!popping) go = OPS::descend(L, v, iso, fetch, stack, track);
             bool done = false, hit = false;
             uint32_t err = 0;
+#ifdef VR_DIAG
+            d_p1 = __builtin_amdgcn_s_memtime();
+            d_acc[7] += __popcll(__ballot(go == VR_GO_EXCLUDED));
+#endif
             if (VR_SWEEP_KEEP && go != VR_GO_MORE && track.upper < seg_upper) {
                 /* `upper` went down since the last return to the root: the state at that return is the newest one
                  * the next walk shares (t, cell, moves and esc have not changed since) */
@@ -1006,8 +1017,17 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 if (L.checked > VR_MAX_CHECKED) { in_root = false; err = 1; }
                 if (in_root) popping = true; else done = true; /* left the volume: a miss (src/raytrace.zig:66-68) */
             }
+#ifdef VR_DIAG
+            d_p2 = __builtin_amdgcn_s_memtime();
+            d_acc[12] += __popcll(__ballot(popping && !done));
+#endif
             /* ---- pop to the lowest ancestor that holds the new point (bounded) ---- */
             if (popping && !done) popping = !OPS::pop(L, stack);
+#ifdef VR_DIAG
+            d_p3 = __builtin_amdgcn_s_memtime();
+            d_acc[13] += __popcll(__ballot(done));
+            d_acc[18] += __ballot(done) ? 1 : 0;
+#endif
 
             if (done) {
                 n_walks++;
@@ -1056,6 +1076,12 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 }
             }
         }
+#ifdef VR_DIAG
+        {
+            const unsigned long long d_p4 = __builtin_amdgcn_s_memtime();
+            d_acc[14] += d_p1 - d_p0; d_acc[15] += d_p2 - d_p1; d_acc[16] += d_p3 - d_p2; d_acc[17] += d_p4 - d_p3;
+        }
+#endif
     }
 
 #ifdef VR_DIAG
@@ -1115,6 +1141,291 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     }
 }
 
+
+/* ------------------------------------------------------------------ union walk ---- */
+
+/* vr_k_union: the sweep as ONE traversal per ray (lane code and the idea: vr_trace_union.h).  Work items are rays;
+ * a lane keeps the 256 done bits of its ray in LDS next to its path stack.  Per-iso counters go through the same
+ * difference arrays in LDS as in vr_k_sweep.  Iso values whose own MOVE does not land on the front's state (a few in
+ * a thousand rays) are written to a list as (ray, run of iso values, own state) and finished by vr_k_union_fix.
+ * Needs node ranges that are nested along every path (a node's range lies inside its parent's), which holds for
+ * every tree built from a volume; uploaded trees are checked (vr_host_ranges_nested). */
+#ifndef VR_UNION_DESCEND_TRIPS
+#define VR_UNION_DESCEND_TRIPS 5
+#endif
+#ifndef VR_UNION_POP_TRIPS
+#define VR_UNION_POP_TRIPS 7
+#endif
+#ifndef VR_UNION_REFILL_MIN
+#define VR_UNION_REFILL_MIN 16
+#endif
+constexpr uint32_t kUnionDescendTrips = VR_UNION_DESCEND_TRIPS, kUnionPopTrips = VR_UNION_POP_TRIPS;
+constexpr uint32_t kUnionRefillMin = VR_UNION_REFILL_MIN;
+constexpr uint32_t kUnionMaxStates = 1u << 20; /* MOVEs of one front: the safety valve (VR_MAX_CHECKED in the other kernels) */
+
+struct VrUnionRecord { uint32_t ray, run, t_bits, cell, esc, pad[3]; }; /* run = r0 | r1 << 8 | in_root << 16 */
+
+template <uint32_t STRIDE>
+struct LdsDone {
+    uint32_t *col; /* this thread's column of the [8][STRIDE] done words */
+    __device__ __forceinline__ uint32_t word(uint32_t w) const { return col[w * STRIDE]; }
+    __device__ __forceinline__ void set(uint32_t w, uint32_t bits) { col[w * STRIDE] |= bits; }
+    __device__ __forceinline__ void clear(uint32_t w) { col[w * STRIDE] = 0u; }
+};
+
+struct UnionSink {
+    unsigned long long *s_checks;
+    uint32_t *s_cnt;
+    uint32_t n_k, iso_begin;
+    uint8_t *rgb;
+    uint64_t frame_bytes;
+    uint32_t pix, ray;
+    uint32_t *except_count;
+    VrUnionRecord *except_list;
+    uint32_t except_cap;
+    __device__ __forceinline__ void add(uint32_t counter, uint32_t r0, uint32_t r1, uint32_t amount)
+    {
+        atomicAdd(&s_cnt[counter * n_k + (r0 - iso_begin)], amount);
+        atomicAdd(&s_cnt[counter * n_k + (r1 + 1u - iso_begin)], 0u - amount);
+    }
+    __device__ __forceinline__ void checks(uint32_t r0, uint32_t r1, uint32_t amount)
+    {
+        atomicAdd(&s_checks[r0 - iso_begin], (unsigned long long)amount);
+        atomicAdd(&s_checks[r1 + 1u - iso_begin], 0ull - (unsigned long long)amount);
+    }
+    /* excluded at a node: the checks of this round and the MOVE out of the node's box, in one 64-bit add each way
+     * (the MOVE count rides in bits 40-63 of the check sums until the block's prefix sums split them) */
+    __device__ __forceinline__ void park(uint32_t r0, uint32_t r1, uint32_t n_checks)
+    {
+        const unsigned long long both = (unsigned long long)n_checks + (1ull << 40);
+        atomicAdd(&s_checks[r0 - iso_begin], both);
+        atomicAdd(&s_checks[r1 + 1u - iso_begin], 0ull - both);
+    }
+    __device__ __forceinline__ void hit(uint32_t r0, uint32_t r1, uint32_t n_checks, float t, uint32_t, uint32_t)
+    {
+        checks(r0, r1, n_checks);
+        add(0u, r0, r1, 1u);
+        const uint8_t g = vr_shade(t); /* shade and store (src/raytrace.zig:56-61), one frame per iso value */
+        uint8_t *p = rgb + (uint64_t)(r0 - iso_begin) * frame_bytes + (uint64_t)pix * 3u;
+        for (uint32_t k = r0; k <= r1; k++, p += frame_bytes) { p[0] = g; p[1] = g; p[2] = g; }
+    }
+    __device__ __forceinline__ void miss(uint32_t r0, uint32_t r1) { add(1u, r0, r1, 1u); }
+    __device__ __forceinline__ void esc(uint32_t r0, uint32_t r1, uint32_t n) { add(3u, r0, r1, n); }
+    __device__ __forceinline__ void error(uint32_t r0, uint32_t r1) { add(4u, r0, r1, 1u); }
+    __device__ __forceinline__ void except(uint32_t r0, uint32_t r1, float t, uint32_t cell, bool in_root, uint32_t n_esc)
+    {
+        const uint32_t at = atomicAdd(except_count, 1u);
+        if (at >= except_cap) { error(r0, r1); return; } /* never seen: the list holds 65536 runs */
+        VrUnionRecord rec;
+        rec.ray = ray; rec.run = r0 | (r1 << 8) | ((in_root ? 1u : 0u) << 16);
+        rec.t_bits = __builtin_bit_cast(uint32_t, t); rec.cell = cell; rec.esc = n_esc;
+        rec.pad[0] = rec.pad[1] = rec.pad[2] = 0u;
+        except_list[at] = rec;
+    }
+};
+
+__global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
+    VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top, uint32_t stack_rows, const float4 *__restrict__ ray_dt,
+    const uint32_t *__restrict__ ray_pix, const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ head, uint32_t iso_begin,
+    uint32_t iso_count, uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
+    VrUnionRecord *__restrict__ except_list, uint32_t except_cap, uint32_t items_per_lane, uint32_t launch_seq)
+{
+    /* dynamic LDS: [path stacks][check sums and counters as in vr_k_sweep][done bits: 8 x kTraceThreads words][top node words] */
+    extern __shared__ uint32_t s_dyn[];
+    unsigned long long *s_checks = (unsigned long long *)(s_dyn + stack_rows * kTraceThreads);
+    uint32_t *s_cnt = (uint32_t *)(s_checks + (iso_count + 1u));
+    uint32_t *s_done = s_dyn + stack_rows * kTraceThreads + sweep_stat_words(iso_count);
+    uint32_t *s_top = s_done + 8u * kTraceThreads;
+    const uint32_t n_k = iso_count + 1u;
+    for (uint32_t i = threadIdx.x; i < sweep_stat_words(iso_count); i += kTraceThreads) s_dyn[stack_rows * kTraceThreads + i] = 0u;
+    for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_top[i] = nodes[i];
+    __syncthreads();
+    LdsStack<kTraceThreads> stack;
+    LdsDone<kTraceThreads> done{ s_done + threadIdx.x };
+    const TopFetch fetch(nodes, s_top, n_top, v.n_slots);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_active = *n_active_ptr;
+    /* work items: (ray, block of iso values), numbered as in vr_k_sweep; one front per item.  Blocks shorten the longest
+     * walk and fill the lanes when there are about as many rays as lanes; each costs the states its iso values share
+     * with the other blocks of the ray once more. */
+    const uint64_t want = (uint64_t)gridDim.x * kTraceThreads * items_per_lane;
+    uint32_t nb = (uint32_t)((want + n_active - 1u) / (n_active ? n_active : 1u));
+    nb = nb < 1u ? 1u : (nb > VR_SWEEP_MAX_BLOCKS ? VR_SWEEP_MAX_BLOCKS : nb);
+    nb = nb > iso_count ? iso_count : nb;
+    const uint32_t block_isos = (iso_count + nb - 1u) / nb, n_blocks = (iso_count + block_isos - 1u) / block_isos;
+    const uint32_t n_items = ((n_active + 63u) & ~63u) * n_blocks;
+    unsigned long long *info = (unsigned long long *)(n_active_ptr + 16);
+    const unsigned long long tick_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tick_empty = 0;
+    uint32_t n_walks = 0;
+
+    UnionSink sink;
+    sink.s_checks = s_checks; sink.s_cnt = s_cnt; sink.n_k = n_k; sink.iso_begin = iso_begin;
+    sink.rgb = rgb; sink.frame_bytes = frame_pixels * 3u; sink.pix = 0; sink.ray = 0;
+    sink.except_count = (uint32_t *)n_active_ptr + 32; sink.except_list = except_list; sink.except_cap = except_cap;
+
+    VrUnionLane U;
+    VrUnionExit x;
+    x.ex = 0; x.sh = 0; x.esc = 0; x.in_root = false;
+    WaveChunk chunk;
+    uint32_t depth_k = 0, cell_before = 0, n_states = 0;
+    bool alive = false, exhausted = false, popping = false, suspect = false;
+
+    for (;;) {
+        /* ---- refill idle lanes from the ray queue ---- */
+        const unsigned long long idle = __ballot(!alive);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (!exhausted && n_idle >= kUnionRefillMin) {
+            uint32_t mine;
+            const bool got = chunk.take(n_idle, (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), head, n_items, n_idle, lane, mine);
+            if (!alive && got) {
+                const uint32_t grp = mine / (64u * n_blocks), in = mine - grp * 64u * n_blocks;
+                const uint32_t blk = in >> 6, ray = grp * 64u + (in & 63u);
+                if (ray < n_active) { /* the last group of 64 may be short */
+                    const float4 r = ray_dt[ray];
+                    sink.pix = ray_pix[ray];
+                    sink.ray = ray;
+                    const uint32_t b0 = blk * block_isos, b1 = b0 + block_isos < iso_count ? b0 + block_isos : iso_count;
+                    vr_union_begin(U, stack, done, v, r.x, r.y, r.z, r.w, iso_begin + b0, b1 - b0);
+                    alive = true; popping = false; n_states = 0;
+                    n_walks++;
+                }
+            }
+            exhausted = chunk.exhausted();
+            if (exhausted && !tick_empty) tick_empty = __builtin_amdgcn_s_memrealtime();
+        }
+        if (__ballot(alive) == 0ull) {
+            if (exhausted) break;
+            continue; /* fewer idle lanes than a refill takes cannot happen with nobody alive, but stay safe */
+        }
+        if (alive) {
+            uint32_t go = VR_GO_MORE;
+            if (!popping) go = vr_union_descend(U, fetch, stack, done, sink, kUnionDescendTrips);
+            if (go == VR_GO_EXCLUDED) {
+                if (U.alive_lo > U.alive_hi) {
+                    alive = false; /* every iso value of the ray has hit */
+                } else {
+                    depth_k = stack.depth(); cell_before = U.L.cell;
+                    x = vr_union_move(U.L, v);
+                    suspect = x.esc != 0u;
+                    if (++n_states > kUnionMaxStates) { /* safety valve: the iso values left are reported as errors */
+                        vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); });
+                        alive = false;
+                    } else if (!x.in_root) {
+                        /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
+                        const float t_new = U.L.t;
+                        vr_union_leave(U.L, stack, x, suspect);
+                        if (suspect) vr_union_resolve(U, v, fetch, done, sink, depth_k, cell_before, -1, t_new, 0u, false);
+                        if (U.alive_lo <= U.alive_hi)
+                            vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1); });
+                        alive = false;
+                    } else {
+                        popping = true;
+                    }
+                }
+            }
+            if (popping && alive) {
+                if (vr_union_pop(U.L, stack, kUnionPopTrips, x, suspect)) {
+                    popping = false;
+                    if (suspect)
+                        vr_union_resolve(U, v, fetch, done, sink, depth_k, cell_before, (int)stack.depth() - 1, U.L.t, U.L.cell, true);
+                    vr_union_after_pop(U, fetch);
+                    if (U.alive_lo > U.alive_hi) alive = false;
+                }
+            }
+        }
+    }
+
+    {
+        const uint32_t w_walks = wave_sum(n_walks);
+        if (lane == 0) {
+            atomicAdd(&s_cnt[kSweepCounters * n_k], w_walks);
+            if ((threadIdx.x >> 6) == 0u) {
+                atomicMin(&info[2], tick_begin);
+                if (tick_empty) atomicMin(&info[3], tick_empty);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&info[0], (unsigned long long)s_cnt[kSweepCounters * n_k]);
+        if (blockIdx.x == 0) { info[1] = n_active * n_blocks; info[5] = launch_seq; }
+        atomicMax(&info[4], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+    if (threadIdx.x < kSweepCounters) {
+        uint32_t *c = s_cnt + threadIdx.x * n_k;
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < iso_count; k++) { run += c[k]; c[k] = run; }
+    } else if (threadIdx.x == kSweepCounters) {
+        unsigned long long run = 0;
+        for (uint32_t k = 0; k < iso_count; k++) { run += s_checks[k]; s_checks[k] = run; }
+    }
+    __syncthreads();
+    if (stats) {
+        for (uint32_t k = threadIdx.x; k < iso_count; k += kTraceThreads) {
+            vr_render_stats *s = stats + k;
+            add_stat(&s->nodes_checked, s_checks[k] & ((1ull << 40) - 1ull));
+            add_stat(&s->hit_count, s_cnt[k]);
+            add_stat(&s->miss_count, s_cnt[n_k + k]);
+            add_stat(&s->moves, (s_checks[k] >> 40) + s_cnt[2u * n_k + k]);
+            add_stat(&s->escape_help_events, s_cnt[3u * n_k + k]);
+            add_stat(&s->errors, s_cnt[4u * n_k + k]);
+        }
+    }
+}
+
+/* The iso values that left the union walk: each is traced on its own from its own state (the checks and the MOVE of
+ * the round that parked it are counted already, its escape helps of that MOVE come with the record). */
+__global__ __launch_bounds__(64) void vr_k_union_fix(VrViewK v, const uint32_t *__restrict__ nodes, const float4 *__restrict__ ray_dt,
+                                                     const uint32_t *__restrict__ ray_pix, const uint32_t *__restrict__ n_active_ptr,
+                                                     const VrUnionRecord *__restrict__ list, uint32_t cap, uint32_t iso_begin,
+                                                     uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats)
+{
+    uint32_t count = n_active_ptr[32];
+    count = count < cap ? count : cap;
+    LdsStack<64u> st; /* dynamic LDS: [levels + 1][64] */
+    /* one wave per record, a lane per iso value of its run */
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const VrUnionRecord rec = list[i];
+        const float4 r = ray_dt[rec.ray];
+        const uint32_t pix = ray_pix[rec.ray];
+        const uint32_t r0 = rec.run & 0xffu, r1 = (rec.run >> 8) & 0xffu;
+        const bool in_root = (rec.run >> 16) & 1u;
+        VrLane A;
+        vr_lane_begin(A, st, v, r.x, r.y, r.z, r.w);
+        for (uint32_t iso = r0 + threadIdx.x; iso <= r1; iso += 64u) {
+            uint32_t moves = 0, esc = rec.esc, err = 0;
+            bool hit = false;
+            A.checked = 0;
+            if (in_root) {
+                vr_lane_restart(A, st, v, __builtin_bit_cast(float, rec.t_bits), rec.cell);
+                for (;;) {
+                    const uint32_t go = vr_lane_descend(A, iso, GlobalFetch{ nodes }, st, 64u);
+                    if (go == VR_GO_MORE) continue;
+                    if (go == VR_GO_HIT) { hit = true; break; }
+                    moves++;
+                    if (A.checked > VR_MAX_CHECKED) { err = 1; break; }
+                    if (!vr_lane_move(A, v, esc)) break;
+                    while (!vr_lane_pop(A, st, 64u)) {}
+                }
+            }
+            if (stats) {
+                vr_render_stats *s = stats + (iso - iso_begin);
+                add_stat(&s->nodes_checked, A.checked);
+                add_stat(hit ? &s->hit_count : &s->miss_count, 1ull);
+                add_stat(&s->moves, moves);
+                add_stat(&s->escape_help_events, esc);
+                add_stat(&s->errors, err);
+            }
+            if (hit) {
+                const uint8_t g = vr_shade(A.t);
+                uint8_t *p = rgb + ((uint64_t)(iso - iso_begin) * frame_pixels + pix) * 3u;
+                p[0] = g; p[1] = g; p[2] = g;
+            }
+        }
+    }
+}
 
 /* ------------------------------------------------------------------ wide volumes ---- */
 
@@ -1395,7 +1706,8 @@ hipError_t vr_device_setup(int device)
     const void *fns[] = { (const void *)vr_k_trace<false>,      (const void *)vr_k_trace<true>,
                           (const void *)vr_k_sweep<false, SweepNarrow>, (const void *)vr_k_sweep<true, SweepNarrow>,
                           (const void *)vr_k_sweep<false, SweepWide>,   (const void *)vr_k_sweep<true, SweepWide>,
-                          (const void *)vr_k_trace_wide<false>, (const void *)vr_k_trace_wide<true> };
+                          (const void *)vr_k_trace_wide<false>, (const void *)vr_k_trace_wide<true>,
+                          (const void *)vr_k_union };
     for (const void *fn : fns)
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u))) != hipSuccess) return e;
     void *p = nullptr;
@@ -1432,6 +1744,7 @@ size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso
     bytes += 256;                                               /* n_active   */
     bytes += sizeof(WaveStats) * kSlotIsoMax * kSlotWaveMax;    /* per-wave counters of short iso ranges */
     bytes += ((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255; /* queue heads */
+    bytes += (size_t)VR_UNION_EXCEPT_CAP * sizeof(VrUnionRecord);          /* iso runs that left a union walk */
     return bytes;
 }
 
@@ -1453,10 +1766,12 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                             const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
                             const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end,
-                            uint32_t sweep_items_per_lane, uint32_t launch_seq)
+                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested)
 {
     const uint32_t n_rows = row_end - row_begin;
     const uint32_t stack_levels = max_depth > 0 ? max_depth : 1u;
+    const bool want_union = variant == VR_KERNEL_UNION;
+    if (want_union) variant = VR_KERNEL_DEFAULT;
     {
         /* the persistent kernel adds 32-bit offsets to the low word of the node array's address */
         const uintptr_t p = (uintptr_t)d_nodes_prepared, last = p + (view.n_slots + 1u) * sizeof(uint32_t) - 1u;
@@ -1497,7 +1812,10 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
     /* a block of iso values: the sweep kernel, which shares traversals between iso values (for fewer than 8 the
      * kernel with one traversal per iso value is as fast or a little faster) */
-    const bool sweep = variant == VR_KERNEL_SWEEP || (use_default && iso_count >= 8u);
+    const bool sweep = variant == VR_KERNEL_SWEEP || want_union || (use_default && iso_count >= VR_UNION_MIN_ISOS);
+    /* one traversal per ray for the whole iso range (vr_k_union) where it applies: no taps (the per-pixel check counts
+     * need one walk per iso value) and node ranges nested along every path; else traversals shared between iso values */
+    const bool use_union = sweep && variant != VR_KERNEL_SWEEP && !any_tap && ranges_nested;
     Prepass pp;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
                             VR_FLAG_OOB << 24, workspace, pp)) != hipSuccess)
@@ -1509,7 +1827,8 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
      * left of its share of the CU's 160 KiB, the top K levels of the tree (two thirds of all node reads).
      * More than one iso value: the sweep kernel, which shares traversals between iso values. */
     const size_t trace_stack_bytes = ((size_t)stack_levels + 1u) * kTraceThreads * sizeof(uint32_t);
-    const size_t stat_bytes = sweep ? (size_t)sweep_stat_words(iso_count) * sizeof(uint32_t) : 0u;
+    const size_t stat_bytes = (sweep ? (size_t)sweep_stat_words(iso_count) * sizeof(uint32_t) : 0u) +
+                              (use_union ? (size_t)8u * kTraceThreads * sizeof(uint32_t) : 0u); /* + the done bits of the union walk */
     const uint32_t top_levels = lds_top_levels(max_depth, view.n_slots, stat_bytes);
     const uint32_t n_top = 1u << top_levels; /* heap positions 0 .. 2^K - 1 = levels 0 .. K-1 (K = 0: the unused slot 0 only) */
     const size_t trace_lds = (size_t)n_top * sizeof(uint32_t) + trace_stack_bytes + stat_bytes;
@@ -1525,14 +1844,26 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     void *args_trace[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                            (void *)&d_rgb, (void *)&d_stats, (void *)&slots, (void *)&taps };
-    void **args = sweep ? args_sweep : args_trace;
-    const void *fn = sweep ? (any_tap ? (const void *)vr_k_sweep<true, SweepNarrow> : (const void *)vr_k_sweep<false, SweepNarrow>)
+    VrUnionRecord *except_list = (VrUnionRecord *)((char *)heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
+    uint32_t except_cap = VR_UNION_EXCEPT_CAP;
+    void *args_union[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
+                           (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
+                           (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
+                           (void *)&launch_seq };
+    void **args = use_union ? args_union : (sweep ? args_sweep : args_trace);
+    const void *fn = use_union ? (const void *)vr_k_union
+                   : sweep ? (any_tap ? (const void *)vr_k_sweep<true, SweepNarrow> : (const void *)vr_k_sweep<false, SweepNarrow>)
                            : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
 
     if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
     if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, trace_lds, stream)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+    if (use_union) { /* the few iso values whose own MOVE parted from the front's */
+        hipLaunchKernelGGL(vr_k_union_fix, dim3(2048), dim3(64), (size_t)stack_rows * 64u * sizeof(uint32_t), stream, view,
+                           d_nodes_prepared, ray_dt, ray_pix, n_active, except_list, except_cap, iso_begin, frame_pixels, d_rgb, d_stats);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if (slots) {
         hipLaunchKernelGGL(vr_k_sum_slots, dim3(iso_count), dim3(1024), 0, stream, slots, blocks * (kTraceThreads / 64u), d_stats);
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1567,6 +1898,14 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                     h[6] / (w * 64.0), (double)h[8]);
             fprintf(stderr, "[diag sweep] after the queue was empty: rounds/wave %.0f, alive lanes/round %.1f, hand-overs/wave %.1f\n",
                     h[10] / w, h[11] / (double)(h[10] ? h[10] : 1), h[9] / w);
+            {
+                const double it = (double)h[4];
+                fprintf(stderr,
+                        "[diag sweep] lanes per round: descending %.1f, moving %.1f, popping %.1f, ending a walk %.2f (rounds with one %.0f%%)\n"
+                        "[diag sweep] cycles per round: descend %.0f, move %.0f, pop %.0f, walk end %.0f, refill + hand-overs %.0f\n",
+                        h[2] / it, h[7] / it, h[12] / it, h[13] / it, 100.0 * h[18] / it, h[14] / it, h[15] / it, h[16] / it, h[17] / it,
+                        ((double)h[1] - (double)(h[14] + h[15] + h[16] + h[17])) / it);
+            }
         } else {
         const double w = (double)h[16], it = (double)h[5];
         fprintf(stderr,

@@ -1,0 +1,328 @@
+/*
+ * vr_trace_union.h -- lane code of the union walk: ONE traversal per ray for a whole range of iso values.
+ *
+ * The reference traces a ray once per iso value (src/raytrace.zig:117-255, called per iso value by
+ * src/main.zig:111-138).  The state of such a walk after a MOVE -- t and with it the point -- depends only on the
+ * box it left (src/raytrace.zig:199-246): t = the nearest exit plane of that box + 0.0001, then escape help against
+ * that box.  Walks of different iso values part at a node (one is excluded there and leaves the node's box at once,
+ * the other goes inside and leaves smaller boxes first) and meet again where the ray leaves that node's box: the last
+ * box left inside shares the exit plane, the division has the same operands, t has the same bits.  So ONE front can
+ * visit every state that the walk of any iso value visits, each once:
+ *
+ *   - the front goes into a node while any iso value that is not done yet holds there (min <= iso <= max);
+ *   - the iso values present at a node that its range excludes are "parked": the reference has checked depth + 1
+ *     nodes for them in this round (src/raytrace.zig:162) and MOVEs them out of this node's box; they are present
+ *     again where the front leaves that box;
+ *   - at a leaf every present iso value in the leaf's range hits, at the front's t and cell (src/raytrace.zig:178-187);
+ *   - present at a state whose lowest ancestor holding the point is A: every iso value in A's range that is not
+ *     done (node ranges are nested along a path, so this is what the parked sets add up to);
+ *   - when the front leaves a box B_k and with it the boxes of ancestors B_m, the iso values parked at level m make
+ *     their own MOVE out of B_m.  It lands on the front's state if B_m and B_k share the exit plane on the axis that
+ *     gave the front's t and the front needed no escape help (then the point is outside B_m as well, so neither do
+ *     they).  Anything else is SUSPECT and resolved exactly (vr_union_resolve): the own MOVE of every parked set is
+ *     worked out and compared; iso values whose state differs leave the union walk as an exception and are walked
+ *     on their own from their own state.
+ *
+ * Per-iso counters are sums over the events an iso value was present at, so they go to the sink as (run of iso
+ * values, amount) pairs; a run is a maximal stretch of iso values that are not done.
+ *
+ * Policies (template parameters): Fetch = node read by heap position (prepared array, vr_trace_core.h), Stack = the
+ * path stack cursor of vr_trace_core.h, Done = 256 done bits as eight words (word(w), set(w, bits)), Sink = where
+ * events go: park(r0, r1, checks), hit(r0, r1, checks, t, cell, g), miss(r0, r1), esc(r0, r1, n),
+ * except(r0, r1, t, cell, in_root, esc).
+ */
+#ifndef VR_TRACE_UNION_H
+#define VR_TRACE_UNION_H
+
+#include "vr_trace_core.h"
+
+struct VrUnionLane {
+    VrLane L;                    /* ray, point, current node and its box (checked is not used) */
+    uint32_t prev_mn, prev_mx;   /* range of the parent of the current node ([0, 255] above the root) */
+    uint32_t alive_lo, alive_hi; /* smallest / largest iso value not done; lo > hi: none left */
+    bool holes;                  /* a done iso value may lie between them (never while the hits have come off the ends) */
+};
+
+VR_HD uint32_t vr_f32_bits(float x) { uint32_t b; __builtin_memcpy(&b, &x, 4); return b; }
+VR_HD uint32_t vr_ctz32(uint32_t x) { return (uint32_t)__builtin_ctz(x); }
+VR_HD uint32_t vr_clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
+
+/* calls f(r0, r1) for every maximal run of iso values in [p, q] that are not done */
+template <class Done, class F>
+VR_HD void vr_union_runs(const Done &done, uint32_t p, uint32_t q, F f, bool holes = true)
+{
+    if (!holes) { f(p, q); return; } /* p, q are clipped to [alive_lo, alive_hi] by every caller */
+    uint32_t i = p;
+    while (i <= q) {
+        /* next iso value >= i that is not done */
+        uint32_t w = i >> 5;
+        uint32_t bits = ~done.word(w) >> (i & 31u);
+        if (bits == 0u) { i = (w + 1u) << 5; continue; }
+        i += vr_ctz32(bits);
+        if (i > q) break;
+        /* the run goes on to the next done iso value */
+        uint32_t j = i;
+        for (;;) {
+            w = j >> 5;
+            bits = done.word(w) >> (j & 31u);
+            if (bits != 0u) { j += vr_ctz32(bits); break; }
+            j = (w + 1u) << 5;
+            if (j > q) break;
+        }
+        const uint32_t r1 = j - 1u < q ? j - 1u : q;
+        f(i, r1);
+        i = r1 + 2u; /* r1 + 1 is done or beyond q */
+    }
+}
+
+/* marks [r0, r1] done */
+template <class Done>
+VR_HD void vr_union_mark(Done &done, uint32_t r0, uint32_t r1)
+{
+    for (uint32_t w = r0 >> 5; w <= (r1 >> 5); w++) {
+        const uint32_t a = w == (r0 >> 5) ? (r0 & 31u) : 0u, b = w == (r1 >> 5) ? (r1 & 31u) : 31u;
+        const uint32_t m = (0xffffffffu >> (31u - b)) & (0xffffffffu << a);
+        done.set(w, m);
+    }
+}
+
+/* is any iso value in [mn, mx] not done? */
+template <class Done>
+VR_HD bool vr_union_any(const Done &done, const VrUnionLane &U, uint32_t mn, uint32_t mx)
+{
+    if (U.alive_lo > U.alive_hi || mx < U.alive_lo || mn > U.alive_hi) return false;
+    if (!U.holes || (mn <= U.alive_lo && U.alive_lo <= mx) || (mn <= U.alive_hi && U.alive_hi <= mx)) return true;
+    for (uint32_t w = mn >> 5; w <= (mx >> 5); w++) {
+        const uint32_t a = w == (mn >> 5) ? (mn & 31u) : 0u, b = w == (mx >> 5) ? (mx & 31u) : 31u;
+        const uint32_t m = (0xffffffffu >> (31u - b)) & (0xffffffffu << a);
+        if (~done.word(w) & m) return true;
+    }
+    return false;
+}
+
+/* after marking: pulls alive_lo / alive_hi in to the nearest iso values that are not done */
+template <class Done>
+VR_HD void vr_union_shrink(const Done &done, VrUnionLane &U)
+{
+    while (U.alive_lo <= U.alive_hi) {
+        const uint32_t w = U.alive_lo >> 5, bits = ~done.word(w) >> (U.alive_lo & 31u);
+        if (bits) { U.alive_lo += vr_ctz32(bits); break; }
+        U.alive_lo = (w + 1u) << 5;
+    }
+    while (U.alive_lo <= U.alive_hi) {
+        const uint32_t w = U.alive_hi >> 5, bits = ~done.word(w) << (31u - (U.alive_hi & 31u));
+        if (bits) { U.alive_hi -= vr_clz32(bits); break; }
+        if (w == 0u) { U.alive_lo = 1u; U.alive_hi = 0u; break; }
+        U.alive_hi = (w << 5) - 1u;
+    }
+}
+
+template <class Stack, class Done>
+VR_HD void vr_union_begin(VrUnionLane &U, Stack &stack, Done &done, const VrViewK &v, float dx, float dy, float dz, float t,
+                          uint32_t iso_begin, uint32_t iso_count)
+{
+    vr_lane_begin(U.L, stack, v, dx, dy, dz, t);
+    U.prev_mn = 0u; U.prev_mx = 255u;
+    U.alive_lo = iso_begin; U.alive_hi = iso_begin + iso_count - 1u;
+    U.holes = false;
+    for (uint32_t w = 0; w < 8u; w++) done.clear(w);
+    if (iso_begin > 0u) vr_union_mark(done, 0u, iso_begin - 1u);
+    if (iso_begin + iso_count < 256u) vr_union_mark(done, iso_begin + iso_count, 255u);
+}
+
+/* Goes down from the current node while an iso value that is not done holds, at most max_trips levels.  Returns
+ * VR_GO_MORE (budget used up) or VR_GO_EXCLUDED (nobody goes into the current node, or it was a leaf and its iso
+ * values have hit: the front leaves its box next). */
+template <class Fetch, class Stack, class Done, class Sink>
+VR_HD uint32_t vr_union_descend(VrUnionLane &U, const Fetch &fetch, Stack &stack, Done &done, Sink &sink, uint32_t max_trips)
+{
+    VrLane &L = U.L;
+    for (uint32_t trip = 0; trip < max_trips; trip++) {
+        const uint32_t n = fetch(L.g);
+        const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
+        const uint32_t checks = stack.depth() + 1u; /* root .. this node (src/raytrace.zig:162) */
+        /* present: the parent's range; excluded here: what this node's range leaves out on either side */
+        if (mn > U.prev_mn) {
+            const uint32_t p = U.prev_mn > U.alive_lo ? U.prev_mn : U.alive_lo, q = mn - 1u < U.alive_hi ? mn - 1u : U.alive_hi;
+            if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes);
+        }
+        if (mx < U.prev_mx) {
+            const uint32_t p = mx + 1u > U.alive_lo ? mx + 1u : U.alive_lo, q = U.prev_mx < U.alive_hi ? U.prev_mx : U.alive_hi;
+            if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes);
+        }
+        if (!vr_union_any(done, U, mn, mx)) return VR_GO_EXCLUDED;
+        if (n & VR_N_LEAF) {
+            const uint32_t p = mn > U.alive_lo ? mn : U.alive_lo, q = mx < U.alive_hi ? mx : U.alive_hi;
+            vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.hit(r0, r1, checks, L.t, L.cell, L.g); }, U.holes);
+            vr_union_mark(done, p, q);
+            U.holes = U.holes || (p > U.alive_lo && q < U.alive_hi); /* hits off either end leave no hole */
+            vr_union_shrink(done, U);
+            return VR_GO_EXCLUDED;
+        }
+        const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
+        const bool right = ((L.cell >> sh) & 0xffu) >= part;
+        uint32_t side = right ? L.lo : L.hi;
+        stack.push(side);
+        side = (side & ~(0xffu << sh)) | (part << sh);
+        L.lo = right ? side : L.lo;
+        L.hi = right ? L.hi : side;
+        L.g = vr_twice_plus(L.g, right);
+        U.prev_mn = mn; U.prev_mx = mx;
+    }
+    return VR_GO_MORE;
+}
+
+/* After vr_union_pop has entered the other child of the ancestor that holds the point: the present iso values are the
+ * ones in that ancestor's range. */
+template <class Fetch>
+VR_HD void vr_union_after_pop(VrUnionLane &U, const Fetch &fetch)
+{
+    const uint32_t n = fetch(U.L.g >> 1);
+    U.prev_mn = n & 0xffu; U.prev_mx = (n >> 8) & 0xffu;
+}
+
+/* vr_lane_move (MOVE + escape help, src/raytrace.zig:199-242) that also says which plane gave t: `sh` = the field
+ * shift of that axis, `ex` = the exit planes of the box that was left (max where the ray travels in +, else min). */
+struct VrUnionExit { uint32_t ex, sh, esc; bool in_root; };
+
+VR_HD VrUnionExit vr_union_move(VrLane &L, const VrViewK &v)
+{
+    VrUnionExit x;
+    x.ex = (L.hi & L.posmask) | (L.lo & ~L.posmask);
+    const float tx = vr_plane_t_r((float)(x.ex & 0xffu), v.ox, L.dx, L.rx);
+    const float ty = vr_plane_t_r((float)((x.ex >> 10) & 0xffu), v.oy, L.dy, L.ry);
+    const float tz = vr_plane_t_r((float)((x.ex >> 20) & 0xffu), v.oz, L.dz, L.rz);
+    float t = fminf(fminf(tx, ty), tz);
+    x.sh = t == tx ? 0u : (t == ty ? 10u : 20u);
+    t += 0.0001f;
+    float i = 0.0f;
+    x.esc = 0u;
+    for (;;) {
+        const float px = v.ox + L.dx * t, py = v.oy + L.dy * t, pz = v.oz + L.dz * t;
+        const uint32_t cx = (uint32_t)vr_floor_i32(px), cy = (uint32_t)vr_floor_i32(py), cz = (uint32_t)vr_floor_i32(pz);
+        x.in_root = (cx < v.rdx) & (cy < v.rdy) & (cz < v.rdz);
+        if (!x.in_root) break;
+        L.cell = vr_pack10(cx, cy, cz);
+        if (!vr_box_contains_cell(L.lo, L.hi, L.cell)) break;
+        t += 0.001f * i;
+        i += 1.0f;
+        x.esc++;
+    }
+    L.t = t;
+    return x;
+}
+
+/* vr_lane_pop for the union walk: pops ancestors until one holds the new point and steps into that ancestor's other
+ * child (see vr_lane_pop), checking on the way that every box the point has left shares the front's exit plane
+ * (`suspect` is set otherwise).  At most max_trips levels per call; true when the other child was entered. */
+template <class Stack>
+VR_HD bool vr_union_pop(VrLane &L, Stack &stack, uint32_t max_trips, const VrUnionExit &x, bool &suspect)
+{
+    const uint32_t cg = L.cell | VR_F_GUARD, cp = L.cell + VR_F_ONES;
+    uint32_t next = stack.peek_up(1);
+    uint32_t word = 0;
+    bool left = false, found = false;
+    for (uint32_t trip = 0; trip < max_trips; trip++) {
+        word = next;
+        stack.up();
+        next = stack.peek_up(1);
+        left = (L.g & 1u) == 0u;
+        const uint32_t a_lo = left ? L.lo : word, a_hi = left ? word : L.hi;
+        const uint32_t a = cg - a_lo, b = (a_hi | VR_F_GUARD) - cp;
+        found = ((a & b) & VR_F_GUARD) == VR_F_GUARD;
+        if (found) break;
+        /* the parent's box is left as well: the iso values parked there make their own MOVE out of it */
+        const uint32_t ex_a = (a_hi & L.posmask) | (a_lo & ~L.posmask);
+        suspect = suspect || (((ex_a ^ x.ex) >> x.sh) & 0x3ffu) != 0u;
+        L.lo = a_lo; L.hi = a_hi;
+        L.g >>= 1;
+    }
+    if (!found) return false;
+    const uint32_t cut = left ? L.hi : L.lo, keep = left ? L.lo : L.hi;
+    const uint32_t carry = ((word ^ cut) + 0xffu * VR_F_ONES) & VR_F_GUARD;
+    const uint32_t fm = carry - (carry >> 8);
+    const uint32_t other = (keep & ~fm) | (cut & fm);
+    stack.push(keep);
+    L.lo = left ? other : word;
+    L.hi = left ? word : other;
+    L.g ^= 1u;
+    return true;
+}
+
+/* The front has left the root box: every level of the path is left.  Sets `suspect` if any box on the way up does not
+ * share the front's exit plane. */
+template <class Stack>
+VR_HD void vr_union_leave(VrLane &L, Stack &stack, const VrUnionExit &x, bool &suspect)
+{
+    while (stack.depth() > 0u) {
+        const uint32_t word = stack.peek_up(0);
+        stack.up();
+        const bool left = (L.g & 1u) == 0u;
+        const uint32_t a_lo = left ? L.lo : word, a_hi = left ? word : L.hi;
+        const uint32_t ex_a = (a_hi & L.posmask) | (a_lo & ~L.posmask);
+        suspect = suspect || (((ex_a ^ x.ex) >> x.sh) & 0x3ffu) != 0u;
+        L.lo = a_lo; L.hi = a_hi;
+        L.g >>= 1;
+    }
+}
+
+/* Exact resolution of a suspect MOVE.  The front stood on the node at heap position g_k (level depth_k) with point
+ * cell `cell_before`, left its box and came to the state (t_new, cell_new, in_root_new) with `esc_k` escape helps; its
+ * lowest ancestor that holds the new point is at level `a_level` (all levels left: a_level = -1).  For every level m
+ * in (a_level, depth_k] the iso values parked there (present at m - 1, excluded at m, not done) make their own MOVE
+ * out of the box of level m: same state as the front's -> they get its escape helps, if any; another state -> they
+ * leave the union walk (sink.except) and are marked done.  Walks the path again from the root, in registers. */
+template <class Fetch, class Done, class Sink>
+VR_HD void vr_union_resolve(VrUnionLane &U, const VrViewK &v, const Fetch &fetch, Done &done, Sink &sink, uint32_t depth_k,
+                            uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root_new)
+{
+    VrLane T = U.L; /* the ray; box, node and point are set below */
+    uint32_t g = 1u, lo = 0u, hi = v.root_hi, prev_mn = 0u, prev_mx = 255u;
+    bool marked = false;
+    for (uint32_t m = 0; m <= depth_k; m++) {
+        const uint32_t n = fetch(g);
+        const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
+        if ((int)m > a_level) {
+            T.lo = lo; T.hi = hi; T.cell = cell_before;
+            bool worked_out = false, same = false;
+            VrUnionExit own;
+            own.esc = 0u; own.in_root = false;
+            float own_t = 0.0f;
+            uint32_t own_cell = 0u;
+            auto each = [&](uint32_t r0, uint32_t r1) {
+                if (!worked_out) {
+                    own = vr_union_move(T, v);
+                    own_t = T.t; own_cell = T.cell;
+                    same = own.in_root == in_root_new &&
+                           (!own.in_root || (vr_f32_bits(own_t) == vr_f32_bits(t_new) && own_cell == cell_new));
+                    worked_out = true;
+                }
+                if (!same) { sink.except(r0, r1, own_t, own_cell, own.in_root, own.esc); marked = true; }
+                else if (own.esc) sink.esc(r0, r1, own.esc);
+            };
+            /* runs are taken before anything is marked at this level: marking happens after both sides */
+            uint32_t r_lo[2] = { 1u, 1u }, r_hi[2] = { 0u, 0u };
+            if (mn > prev_mn) { r_lo[0] = prev_mn > U.alive_lo ? prev_mn : U.alive_lo; r_hi[0] = mn - 1u < U.alive_hi ? mn - 1u : U.alive_hi; }
+            if (mx < prev_mx) { r_lo[1] = mx + 1u > U.alive_lo ? mx + 1u : U.alive_lo; r_hi[1] = prev_mx < U.alive_hi ? prev_mx : U.alive_hi; }
+            for (int s = 0; s < 2; s++)
+                if (r_lo[s] <= r_hi[s]) vr_union_runs(done, r_lo[s], r_hi[s], each, U.holes);
+            if (worked_out && !same) {
+                for (int s = 0; s < 2; s++)
+                    if (r_lo[s] <= r_hi[s]) vr_union_mark(done, r_lo[s], r_hi[s]); /* already done ones stay done */
+                U.holes = true;
+            }
+        }
+        if (m == depth_k) break;
+        const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
+        const bool right = ((cell_before >> sh) & 0xffu) >= part;
+        uint32_t side = right ? lo : hi;
+        side = (side & ~(0xffu << sh)) | (part << sh);
+        lo = right ? side : lo;
+        hi = right ? hi : side;
+        g = vr_twice_plus(g, right);
+        prev_mn = mn; prev_mx = mx;
+    }
+    if (marked) vr_union_shrink(done, U);
+}
+
+#endif /* VR_TRACE_UNION_H */
