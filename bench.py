@@ -379,7 +379,7 @@ def main():
     errors = torch.tensor([float(stats[:, 6].sum()) if main_plan.rays else 0.0], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(errors, op=dist.ReduceOp.SUM)
-    sweep_kernel = args.kernel == 5 or (args.kernel == 0 and main_plan.iso_count >= 8)  # both tree formats
+    sweep_kernel = args.kernel in (5, 6) or (args.kernel == 0 and main_plan.iso_count >= 8)  # kernels that report on themselves
     info = None
     if sweep_kernel and main_plan.rays:
         si = capi.SweepInfo()
@@ -388,6 +388,7 @@ def main():
             span = float(si.tick_end - si.tick_begin)
             info = {"walks_per_launch": int(si.walks), "items_per_launch": int(si.items),
                     "items_per_lane": int(si.items_per_lane), "cut_settled": bool(si.cut_settled), "settle_launches": main_settle,
+                    "list_runs": int(si.list_runs),
                     "drain_frac": (si.tick_end - min(si.tick_queue_empty, si.tick_end)) / span,
                     "kernel_span_ms_gpu_clock": span / 1e5}
 
@@ -410,7 +411,7 @@ def main():
         vol_name = {"skull": "Skull.vol", "c60": "C60.vol", "standin256": "256^3 stand-in", "gyroid1024": "1024^3 gyroid"}[args.volume]
         workload = "%s_%dx%d_iso%d-%d_sweep" % (args.volume, W, H, I0, I0 + IN - 1)
         kernel_name = ("vr_k_render_wide" if args.kernel in (1, 2, 3) else "vr_k_sweep" if sweep_kernel else "vr_k_trace_wide") if wide else (
-            {0: "vr_k_sweep" if main_plan.iso_count >= 8 else "vr_k_trace", 4: "vr_k_trace", 5: "vr_k_sweep"}.get(args.kernel, "vr_k_render"))
+            {0: "vr_k_union" if main_plan.iso_count >= 8 else "vr_k_trace", 4: "vr_k_trace", 5: "vr_k_sweep", 6: "vr_k_union"}.get(args.kernel, "vr_k_render"))
         alg_bytes = 4.0 * nodes_checked + 3.0 * main_plan.rays
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         counters, traffic, stale = (None, None, None)

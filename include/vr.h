@@ -369,6 +369,8 @@ typedef struct vr_sweep_info {
     uint64_t tick_begin, tick_queue_empty, tick_end;
     uint32_t items_per_lane; /* the cut of the iso range that launch ran with */
     uint32_t cut_settled;    /* 1 once the context has stopped trying other cuts on this workload */
+    uint32_t list_runs;      /* union kernel: runs of iso values that its second kernel had to finish (normally 0) */
+    uint32_t reserved;
 } vr_sweep_info;
 int vr_sweep_info_read(vr_ctx *ctx, vr_sweep_info *out);
 

@@ -330,13 +330,17 @@ struct HostDone {
     uint32_t w[8];
     uint32_t word(uint32_t i) const { return w[i]; }
     void set(uint32_t i, uint32_t bits) { w[i] |= bits; }
+    void unset(uint32_t i, uint32_t bits) { w[i] &= ~bits; }
     void clear(uint32_t i) { w[i] = 0u; }
+    void fill(uint32_t i) { w[i] = 0xffffffffu; }
 };
 struct HostUnionSink {
     const VrViewK *k; const uint32_t *nodes; const VrLane *ray; /* for iso values that are walked on their own */
     uint32_t iso_begin; uint64_t frame, pix;
     uint8_t *gray; uint32_t *cell_flag; float *t_out; uint32_t *node; uint64_t *sums;
     uint64_t n_except = 0, n_except_isos = 0;
+    /* one run kept for a front of its own, as the kernel's lanes do; further ones are walked iso value by iso value */
+    bool pend = false; float pend_t = 0.0f; uint32_t pend_cell = 0; VrUnionRuns pend_runs = { 0u, 0u, 0u };
     void finish(uint32_t iso, bool hit, float t, uint32_t cell, uint32_t g)
     {
         const uint64_t at = (uint64_t)(iso - iso_begin) * frame + pix;
@@ -361,6 +365,13 @@ struct HostUnionSink {
     void except(uint32_t r0, uint32_t r1, float t, uint32_t cell, bool in_root, uint32_t n_esc)
     {
         n_except++;
+        if (in_root && !pend) { pend = true; pend_t = t; pend_cell = cell; pend_runs.clear(); }
+        if (in_root && cell == pend_cell && vr_f32_bits(t) == vr_f32_bits(pend_t) && pend_runs.room()) {
+            n_except_isos += r1 - r0 + 1u;
+            esc(r0, r1, n_esc);
+            pend_runs.add(r0, r1);
+            return;
+        }
         for (uint32_t iso = r0; iso <= r1; iso++) {
             n_except_isos++;
             sums[(iso - iso_begin) * 7 + 4] += n_esc;
@@ -426,25 +437,30 @@ extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8
             const VrLane ray_lane = U.L;
             HostUnionSink sink{ &k, nodes, &ray_lane, iso_begin, frame, pix, gray, cell_flag, t_out, node, sums };
             const CountingFetch fetch{ nodes, &n_reads, (uint32_t)(n_slots - 1u) & ~1u };
-            while (U.alive_lo <= U.alive_hi) {
-                const uint32_t go = vr_union_descend(U, fetch, st, done, sink, max_trips);
-                if (go == VR_GO_MORE) continue;
-                if (U.alive_lo > U.alive_hi) break;
-                n_states++;
-                const uint32_t depth_k = st.depth(), cell_before = U.L.cell;
-                const VrUnionExit x = vr_union_move(U.L, k);
-                bool suspect = x.esc != 0u;
-                if (!x.in_root) {
-                    const float t_new = U.L.t;
-                    vr_union_leave(U.L, st, x, suspect);
-                    if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false); }
-                    if (U.alive_lo <= U.alive_hi)
-                        vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1, t_new); });
-                    break;
+            for (;;) {
+                while (U.alive_lo <= U.alive_hi) {
+                    const uint32_t go = vr_union_descend(U, fetch, st, done, sink, max_trips);
+                    if (go == VR_GO_MORE) continue;
+                    if (U.alive_lo > U.alive_hi) break;
+                    n_states++;
+                    const uint32_t depth_k = st.depth(), cell_before = U.L.cell;
+                    const VrUnionExit x = vr_union_move(U.L, k);
+                    bool suspect = x.esc != 0u;
+                    if (!x.in_root) {
+                        const float t_new = U.L.t;
+                        vr_union_leave(U.L, st, x, suspect);
+                        if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false); }
+                        if (U.alive_lo <= U.alive_hi)
+                            vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1, t_new); });
+                        break;
+                    }
+                    while (!vr_union_pop(U.L, st, max_trips, x, suspect)) {}
+                    if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, (int)st.depth() - 1, U.L.t, U.L.cell, true); }
+                    vr_union_after_pop(U, HostFetch{ nodes });
                 }
-                while (!vr_union_pop(U.L, st, max_trips, x, suspect)) {}
-                if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, (int)st.depth() - 1, U.L.t, U.L.cell, true); }
-                vr_union_after_pop(U, HostFetch{ nodes });
+                if (!sink.pend) break;
+                sink.pend = false;
+                vr_union_restart(U, st, done, k, sink.pend_t, sink.pend_cell, sink.pend_runs);
             }
             n_except += sink.n_except; n_except_isos += sink.n_except_isos;
         }

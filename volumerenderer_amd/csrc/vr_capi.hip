@@ -57,15 +57,17 @@ struct vr_ctx {
      * scatter by several per cent (which CU gets which item is decided by atomics), so a cut is judged by the shortest
      * of three launches.  For a new workload (tree, image size, iso range) the base cut runs first (8 items per lane
      * for long sweeps, fewer for short ones: sweep_cut_base; the very first launch, on cold caches, does not count),
-     * then the next smaller cut (3/4, 1/2, 1/4 of the base), and on from there while it pays; if the smaller cut did
-     * not pay, the next larger one (11/8, 2x), and on.  A candidate gets exactly three launches, all other launches
-     * use the best cut known; it stays when it was at least 1.5 % shorter.  Results never depend on the cut. */
+     * then the next smaller cut (3/4 of the base) and the next larger one (3/2), and on from the better of the two
+     * (1/2, 1/4 or 2x, 4x) while it pays.  A candidate gets exactly three launches, all other launches use the best
+     * cut known; it stays when it was at least 1.5 % shorter.  Results never depend on the cut.  The kernel with one
+     * traversal per ray and block of iso values is tuned the same way from a smaller base. */
     struct SweepTune {
         uint64_t key = 0;
         uint32_t seq = 0, seen = 0;
         uint32_t base = VR_SWEEP_ITEMS_DEFAULT, best_ipl = VR_SWEEP_ITEMS_DEFAULT;
         uint64_t best_span = 0;
         int dir = 0, step = 0;   /* candidate being tried: sweep_cut_candidate(base, dir, step) */
+        bool down_better = false; /* the first step down beat the base */
         int phase = 0;           /* 0 measuring the default, 1 trying candidates, 2 settled */
         int n_launched = 0, n_reports = 0; /* of the cut being measured */
         uint32_t last_seq = 0;             /* its newest launch */
@@ -473,8 +475,16 @@ static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, 
             } else {
                 const bool better = (double)t.cur_span < 0.985 * (double)t.best_span;
                 if (better) { t.best_ipl = under_test; t.best_span = t.cur_span; }
-                if (better && sweep_cut_candidate(t.base, t.dir, t.step + 1)) t.step++; /* on in the same direction */
-                else if (!better && t.dir < 0 && t.step == 0) t.dir = 1;                /* smaller did not pay: try larger */
+                if (t.step == 0 && t.dir < 0) { /* the first step down is in: the first step up is measured as well */
+                    t.down_better = better;
+                    if (sweep_cut_candidate(t.base, 1, 0)) t.dir = 1;
+                    else if (better) t.step = 1;
+                    else t.phase = 2;
+                } else if (t.step == 0) {       /* both first steps are in: on in the direction of the best one */
+                    if (better) t.step = 1;
+                    else if (t.down_better) { t.dir = -1; t.step = 1; }
+                    else t.phase = 2;
+                } else if (better) t.step++;
                 else t.phase = 2;
             }
             if (t.phase == 1 && !sweep_cut_candidate(t.base, t.dir, t.step)) t.phase = 2;
@@ -858,6 +868,8 @@ int vr_sweep_info_read(vr_ctx *c, vr_sweep_info *out)
     VR_HIP(hipSetDevice(c->device));
     VR_HIP(hipStreamSynchronize(c->stream));
     VR_HIP(hipMemcpy(out, (const char *)c->d_work + c->info_off, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    VR_HIP(hipMemcpy(&out->list_runs, (const char *)c->d_work + c->info_off + 64, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    out->reserved = 0;
     out->items_per_lane = c->last_ipl;
     out->cut_settled = c->tune.phase == 2 ? 1u : 0u;
     return VR_OK;

@@ -1170,7 +1170,9 @@ struct LdsDone {
     uint32_t *col; /* this thread's column of the [8][STRIDE] done words */
     __device__ __forceinline__ uint32_t word(uint32_t w) const { return col[w * STRIDE]; }
     __device__ __forceinline__ void set(uint32_t w, uint32_t bits) { col[w * STRIDE] |= bits; }
+    __device__ __forceinline__ void unset(uint32_t w, uint32_t bits) { col[w * STRIDE] &= ~bits; }
     __device__ __forceinline__ void clear(uint32_t w) { col[w * STRIDE] = 0u; }
+    __device__ __forceinline__ void fill(uint32_t w) { col[w * STRIDE] = 0xffffffffu; }
 };
 
 struct UnionSink {
@@ -1183,6 +1185,18 @@ struct UnionSink {
     uint32_t *except_count;
     VrUnionRecord *except_list;
     uint32_t except_cap;
+    /* iso values that left the front, kept by the lane until an idle lane of the wave takes them or the ray's current
+     * front is finished and the lane walks them itself, as a front of their own; two such states of up to four runs each
+     * fit, more go to the list */
+    bool pend, pend2;
+    float pend_t, pend2_t;
+    uint32_t pend_cell, pend2_cell;
+    VrUnionRuns pend_runs, pend2_runs;
+    __device__ __forceinline__ void pend_shift()
+    {
+        pend = pend2; pend_t = pend2_t; pend_cell = pend2_cell; pend_runs = pend2_runs;
+        pend2 = false;
+    }
     __device__ __forceinline__ void add(uint32_t counter, uint32_t r0, uint32_t r1, uint32_t amount)
     {
         atomicAdd(&s_cnt[counter * n_k + (r0 - iso_begin)], amount);
@@ -1214,6 +1228,28 @@ struct UnionSink {
     __device__ __forceinline__ void error(uint32_t r0, uint32_t r1) { add(4u, r0, r1, 1u); }
     __device__ __forceinline__ void except(uint32_t r0, uint32_t r1, float t, uint32_t cell, bool in_root, uint32_t n_esc)
     {
+        if (!in_root) { /* their own MOVE left the volume: misses (src/raytrace.zig:66-68) */
+            if (n_esc) esc(r0, r1, n_esc);
+            miss(r0, r1);
+            return;
+        }
+        const uint32_t tb = __builtin_bit_cast(uint32_t, t);
+        if (!pend) {
+            pend = true; pend_t = t; pend_cell = cell; pend_runs.clear();
+        }
+        if (cell == pend_cell && tb == __builtin_bit_cast(uint32_t, pend_t) && pend_runs.room()) {
+            if (n_esc) esc(r0, r1, n_esc);
+            pend_runs.add(r0, r1);
+            return;
+        }
+        if (!pend2) {
+            pend2 = true; pend2_t = t; pend2_cell = cell; pend2_runs.clear();
+        }
+        if (cell == pend2_cell && tb == __builtin_bit_cast(uint32_t, pend2_t) && pend2_runs.room()) {
+            if (n_esc) esc(r0, r1, n_esc);
+            pend2_runs.add(r0, r1);
+            return;
+        }
         const uint32_t at = atomicAdd(except_count, 1u);
         if (at >= except_cap) { error(r0, r1); return; } /* never seen: the list holds 65536 runs */
         VrUnionRecord rec;
@@ -1264,13 +1300,25 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     sink.s_checks = s_checks; sink.s_cnt = s_cnt; sink.n_k = n_k; sink.iso_begin = iso_begin;
     sink.rgb = rgb; sink.frame_bytes = frame_pixels * 3u; sink.pix = 0; sink.ray = 0;
     sink.except_count = (uint32_t *)n_active_ptr + 32; sink.except_list = except_list; sink.except_cap = except_cap;
-
+    sink.pend = false; sink.pend_t = 0.0f; sink.pend_cell = 0; sink.pend_runs.clear();
+    sink.pend2 = false; sink.pend2_t = 0.0f; sink.pend2_cell = 0; sink.pend2_runs.clear();
     VrUnionLane U;
     VrUnionExit x;
     x.ex = 0; x.sh = 0; x.esc = 0; x.in_root = false;
     WaveChunk chunk;
     uint32_t depth_k = 0, cell_before = 0, n_states = 0;
     bool alive = false, exhausted = false, popping = false, suspect = false;
+    /* the front of a lane is finished: on with the run it has kept, if any, else the lane is idle */
+    auto front_done = [&](bool &alive_, bool &popping_) {
+        if (sink.pend) {
+            vr_union_restart(U, stack, done, v, sink.pend_t, sink.pend_cell, sink.pend_runs);
+            sink.pend_shift();
+            popping_ = false;
+        } else {
+            alive_ = false;
+        }
+    };
+
 
     for (;;) {
         /* ---- refill idle lanes from the ray queue ---- */
@@ -1304,13 +1352,14 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             if (!popping) go = vr_union_descend(U, fetch, stack, done, sink, kUnionDescendTrips);
             if (go == VR_GO_EXCLUDED) {
                 if (U.alive_lo > U.alive_hi) {
-                    alive = false; /* every iso value of the ray has hit */
+                    front_done(alive, popping); /* every iso value of the front has hit */
                 } else {
                     depth_k = stack.depth(); cell_before = U.L.cell;
                     x = vr_union_move(U.L, v);
                     suspect = x.esc != 0u;
                     if (++n_states > kUnionMaxStates) { /* safety valve: the iso values left are reported as errors */
                         vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); });
+                        sink.pend = false; sink.pend2 = false;
                         alive = false;
                     } else if (!x.in_root) {
                         /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
@@ -1319,7 +1368,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                         if (suspect) vr_union_resolve(U, v, fetch, done, sink, depth_k, cell_before, -1, t_new, 0u, false);
                         if (U.alive_lo <= U.alive_hi)
                             vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1); });
-                        alive = false;
+                        front_done(alive, popping);
                     } else {
                         popping = true;
                     }
@@ -1331,8 +1380,30 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     if (suspect)
                         vr_union_resolve(U, v, fetch, done, sink, depth_k, cell_before, (int)stack.depth() - 1, U.L.t, U.L.cell, true);
                     vr_union_after_pop(U, fetch);
-                    if (U.alive_lo > U.alive_hi) alive = false;
+                    if (U.alive_lo > U.alive_hi) front_done(alive, popping);
                 }
+            }
+        }
+        /* ---- a run that has left a lane's front goes to an idle lane of the wave, if there is one: a front of its own,
+         * walked at the same time instead of after the ray's front (which is often the longest of the wave) ---- */
+        for (;;) {
+            const unsigned long long givers = __ballot(alive && sink.pend), takers = __ballot(!alive);
+            if (givers == 0ull || takers == 0ull) break;
+            const uint32_t giver = (uint32_t)__ffsll((long long)givers) - 1u, taker = (uint32_t)__ffsll((long long)takers) - 1u;
+            const float g_t = lane_f(sink.pend_t, giver);
+            const uint32_t g_cell = (uint32_t)__builtin_amdgcn_readlane((int)sink.pend_cell, giver);
+            VrUnionRuns g_runs;
+            g_runs.n = (uint32_t)__builtin_amdgcn_readlane((int)sink.pend_runs.n, giver);
+            g_runs.w01 = (uint32_t)__builtin_amdgcn_readlane((int)sink.pend_runs.w01, giver);
+            g_runs.w23 = (uint32_t)__builtin_amdgcn_readlane((int)sink.pend_runs.w23, giver);
+            const uint32_t g_pix = (uint32_t)__builtin_amdgcn_readlane((int)sink.pix, giver);
+            const uint32_t g_ray = (uint32_t)__builtin_amdgcn_readlane((int)sink.ray, giver);
+            SweepNarrow::adopt(U.L, giver, lane == taker);
+            if (lane == giver) sink.pend_shift();
+            if (lane == taker) {
+                sink.pix = g_pix; sink.ray = g_ray;
+                vr_union_restart(U, stack, done, v, g_t, g_cell, g_runs);
+                alive = true; popping = false; n_states = 0;
             }
         }
     }

@@ -27,7 +27,7 @@
  * values, amount) pairs; a run is a maximal stretch of iso values that are not done.
  *
  * Policies (template parameters): Fetch = node read by heap position (prepared array, vr_trace_core.h), Stack = the
- * path stack cursor of vr_trace_core.h, Done = 256 done bits as eight words (word(w), set(w, bits)), Sink = where
+ * path stack cursor of vr_trace_core.h, Done = 256 done bits as eight words (word, set, unset, clear, fill), Sink = where
  * events go: park(r0, r1, checks), hit(r0, r1, checks, t, cell, g), miss(r0, r1), esc(r0, r1, n),
  * except(r0, r1, t, cell, in_root, esc).
  */
@@ -128,6 +128,43 @@ VR_HD void vr_union_begin(VrUnionLane &U, Stack &stack, Done &done, const VrView
     for (uint32_t w = 0; w < 8u; w++) done.clear(w);
     if (iso_begin > 0u) vr_union_mark(done, 0u, iso_begin - 1u);
     if (iso_begin + iso_count < 256u) vr_union_mark(done, iso_begin + iso_count, 255u);
+}
+
+/* Up to four runs of iso values, in any order, as byte pairs (lo, hi) in two words: what has left a front at one state
+ * (an excluding node's range has a side below and one above; ancestors that share its exit plane add theirs). */
+struct VrUnionRuns {
+    uint32_t n, w01, w23;
+    VR_HD void clear() { n = 0u; w01 = 0u; w23 = 0u; }
+    VR_HD uint32_t lo(uint32_t i) const { return ((i < 2u ? w01 : w23) >> ((i & 1u) * 16u)) & 0xffu; }
+    VR_HD uint32_t hi(uint32_t i) const { return ((i < 2u ? w01 : w23) >> ((i & 1u) * 16u + 8u)) & 0xffu; }
+    VR_HD bool room() const { return n < 4u; }
+    VR_HD void add(uint32_t r0, uint32_t r1)
+    {
+        const uint32_t pair = (r0 | (r1 << 8)) << ((n & 1u) * 16u);
+        if (n < 2u) w01 |= pair; else w23 |= pair;
+        n++;
+    }
+};
+
+/* A new front for the runs `runs` of iso values of the same ray from the state (t, cell): what iso values that left the
+ * union walk carry on with (their own MOVE has been made and counted; the reference returns to the root next). */
+template <class Stack, class Done>
+VR_HD void vr_union_restart(VrUnionLane &U, Stack &stack, Done &done, const VrViewK &v, float t, uint32_t cell, const VrUnionRuns &runs)
+{
+    vr_lane_restart(U.L, stack, v, t, cell);
+    U.prev_mn = 0u; U.prev_mx = 255u;
+    U.alive_lo = 255u; U.alive_hi = 0u;
+    U.holes = runs.n > 1u;
+    for (uint32_t w = 0; w < 8u; w++) done.fill(w); /* everything done but the runs */
+    for (uint32_t i = 0; i < runs.n; i++) {
+        const uint32_t r0 = runs.lo(i), r1 = runs.hi(i);
+        U.alive_lo = r0 < U.alive_lo ? r0 : U.alive_lo;
+        U.alive_hi = r1 > U.alive_hi ? r1 : U.alive_hi;
+        for (uint32_t w = r0 >> 5; w <= (r1 >> 5); w++) {
+            const uint32_t a = w == (r0 >> 5) ? (r0 & 31u) : 0u, b = w == (r1 >> 5) ? (r1 & 31u) : 31u;
+            done.unset(w, (0xffffffffu >> (31u - b)) & (0xffffffffu << a));
+        }
+    }
 }
 
 /* Goes down from the current node while an iso value that is not done holds, at most max_trips levels.  Returns
