@@ -451,7 +451,7 @@ extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8
                         vr_union_leave(U.L, st, x, suspect);
                         if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false); }
                         if (U.alive_lo <= U.alive_hi)
-                            vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1, t_new); });
+                            vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1, t_new); }, U.holes);
                         break;
                     }
                     while (!vr_union_pop(U.L, st, max_trips, x, suspect)) {}

@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     x = vr_union_move(U.L, v);
                     suspect = x.esc != 0u;
                     if (++n_states > kUnionMaxStates) { /* safety valve: the iso values left are reported as errors */
-                        vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); });
+                        vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); }, U.holes);
                         sink.pend = false; sink.pend2 = false;
                         alive = false;
                     } else if (!x.in_root) {
@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                         vr_union_leave(U.L, stack, x, suspect);
                         if (suspect) vr_union_resolve(U, v, fetch, done, sink, depth_k, cell_before, -1, t_new, 0u, false);
                         if (U.alive_lo <= U.alive_hi)
-                            vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1); });
+                            vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1); }, U.holes);
                         front_done(alive, popping);
                     } else {
                         popping = true;

@@ -40,7 +40,8 @@ struct VrUnionLane {
     VrLane L;                    /* ray, point, current node and its box (checked is not used) */
     uint32_t prev_mn, prev_mx;   /* range of the parent of the current node ([0, 255] above the root) */
     uint32_t alive_lo, alive_hi; /* smallest / largest iso value not done; lo > hi: none left */
-    bool holes;                  /* a done iso value may lie between them (never while the hits have come off the ends) */
+    bool holes;                  /* a done iso value may lie between them (never while the hits have come off the ends);
+                                  * the done bits are kept only from then on, and only between alive_lo and alive_hi */
 };
 
 VR_HD uint32_t vr_f32_bits(float x) { uint32_t b; __builtin_memcpy(&b, &x, 4); return b; }
@@ -49,7 +50,7 @@ VR_HD uint32_t vr_clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
 
 /* calls f(r0, r1) for every maximal run of iso values in [p, q] that are not done */
 template <class Done, class F>
-VR_HD void vr_union_runs(const Done &done, uint32_t p, uint32_t q, F f, bool holes = true)
+VR_HD void vr_union_runs(const Done &done, uint32_t p, uint32_t q, F f, bool holes)
 {
     if (!holes) { f(p, q); return; } /* p, q are clipped to [alive_lo, alive_hi] by every caller */
     uint32_t i = p;
@@ -92,12 +93,22 @@ VR_HD bool vr_union_any(const Done &done, const VrUnionLane &U, uint32_t mn, uin
 {
     if (U.alive_lo > U.alive_hi || mx < U.alive_lo || mn > U.alive_hi) return false;
     if (!U.holes || (mn <= U.alive_lo && U.alive_lo <= mx) || (mn <= U.alive_hi && U.alive_hi <= mx)) return true;
+    /* strictly inside (alive_lo, alive_hi) here: the bits are valid */
     for (uint32_t w = mn >> 5; w <= (mx >> 5); w++) {
         const uint32_t a = w == (mn >> 5) ? (mn & 31u) : 0u, b = w == (mx >> 5) ? (mx & 31u) : 31u;
         const uint32_t m = (0xffffffffu >> (31u - b)) & (0xffffffffu << a);
         if (~done.word(w) & m) return true;
     }
     return false;
+}
+
+/* The first done iso value strictly inside the alive range is about to be marked: from here on the bits count. */
+template <class Done>
+VR_HD void vr_union_need_bits(Done &done, VrUnionLane &U)
+{
+    if (U.holes) return;
+    for (uint32_t w = 0; w < 8u; w++) done.clear(w);
+    U.holes = true;
 }
 
 /* after marking: pulls alive_lo / alive_hi in to the nearest iso values that are not done */
@@ -125,9 +136,7 @@ VR_HD void vr_union_begin(VrUnionLane &U, Stack &stack, Done &done, const VrView
     U.prev_mn = 0u; U.prev_mx = 255u;
     U.alive_lo = iso_begin; U.alive_hi = iso_begin + iso_count - 1u;
     U.holes = false;
-    for (uint32_t w = 0; w < 8u; w++) done.clear(w);
-    if (iso_begin > 0u) vr_union_mark(done, 0u, iso_begin - 1u);
-    if (iso_begin + iso_count < 256u) vr_union_mark(done, iso_begin + iso_count, 255u);
+    (void)done;
 }
 
 /* Up to four runs of iso values, in any order, as byte pairs (lo, hi) in two words: what has left a front at one state
@@ -155,6 +164,7 @@ VR_HD void vr_union_restart(VrUnionLane &U, Stack &stack, Done &done, const VrVi
     U.prev_mn = 0u; U.prev_mx = 255u;
     U.alive_lo = 255u; U.alive_hi = 0u;
     U.holes = runs.n > 1u;
+    if (!U.holes) { U.alive_lo = runs.lo(0u); U.alive_hi = runs.hi(0u); return; }
     for (uint32_t w = 0; w < 8u; w++) done.fill(w); /* everything done but the runs */
     for (uint32_t i = 0; i < runs.n; i++) {
         const uint32_t r0 = runs.lo(i), r1 = runs.hi(i);
@@ -191,9 +201,14 @@ VR_HD uint32_t vr_union_descend(VrUnionLane &U, const Fetch &fetch, Stack &stack
         if (n & VR_N_LEAF) {
             const uint32_t p = mn > U.alive_lo ? mn : U.alive_lo, q = mx < U.alive_hi ? mx : U.alive_hi;
             vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.hit(r0, r1, checks, L.t, L.cell, L.g); }, U.holes);
-            vr_union_mark(done, p, q);
-            U.holes = U.holes || (p > U.alive_lo && q < U.alive_hi); /* hits off either end leave no hole */
-            vr_union_shrink(done, U);
+            if (!U.holes && (p == U.alive_lo || q == U.alive_hi)) { /* hits off either end leave no hole */
+                if (p == U.alive_lo) U.alive_lo = q + 1u; /* past alive_hi when both ends went: none left */
+                else U.alive_hi = p - 1u;
+            } else {
+                vr_union_need_bits(done, U);
+                vr_union_mark(done, p, q);
+                vr_union_shrink(done, U);
+            }
             return VR_GO_EXCLUDED;
         }
         const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
@@ -344,9 +359,9 @@ VR_HD void vr_union_resolve(VrUnionLane &U, const VrViewK &v, const Fetch &fetch
             for (int s = 0; s < 2; s++)
                 if (r_lo[s] <= r_hi[s]) vr_union_runs(done, r_lo[s], r_hi[s], each, U.holes);
             if (worked_out && !same) {
+                vr_union_need_bits(done, U);
                 for (int s = 0; s < 2; s++)
                     if (r_lo[s] <= r_hi[s]) vr_union_mark(done, r_lo[s], r_hi[s]); /* already done ones stay done */
-                U.holes = true;
             }
         }
         if (m == depth_k) break;
