@@ -10,6 +10,10 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+# the cut of the iso range that the library settles on for this workload (an un-profiled run with the usual settling), forced
+# for the profiled runs below so that every traced launch runs with it
+cut=$(timeout -k 10 300 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-delivered "$@" 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline'].get('items_per_lane') or '')")
+if [ -n "$cut" ]; then export VR_SWEEP_ITEMS=$cut; echo "settled cut: $cut items per lane"; fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 5 --warmup 1 --settle 0 --no-cpu-baseline --no-host-delivered "$@" > $out/bench_trace.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
 i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
@@ -35,7 +39,7 @@ for name in ["vr_kernels.hip", "vr_trace_core.h", "vr_trace_wide.h"]:
     h.update(open(os.path.join(root, "volumerenderer_amd", "csrc", name), "rb").read())
 summary = {"workload": workload, "commit": commit, "kernel_sources_sha": h.hexdigest()[:16],
            "command": "rocprofv3 --pmc <one pass per run> -- python3 bench.py --steps 2 --warmup 1 --settle 0 --no-cpu-baseline --no-host-delivered " + " ".join(sys.argv[4:]),
-           "note": "per-dispatch means; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (gfx950: double FETCH_SIZE)",
+           "forced_items_per_lane": os.environ.get("VR_SWEEP_ITEMS"), "note": "per-dispatch means; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (gfx950: double FETCH_SIZE)",
            "bench_under_trace": {k: bench[k] for k in ("value", "ms_per_step")}, "kernel_ms_under_trace": bench["roofline"]["kernel_ms"],
            "kernels": {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}}
 json.dump(summary, open("%s/r02_pmc_%s.json" % (out, workload), "w"), indent=1)
