@@ -36,6 +36,16 @@
 
 #include "vr_trace_core.h"
 
+/* The lane code of a front is large (runs of iso values, both sides of a range, exact resolution): what is rare is kept
+ * out of line and the level loop is not unrolled, so that the kernel's loop stays inside the instruction cache. */
+#if defined(__clang__)
+#define VR_ROLLED _Pragma("unroll 1")
+#define VR_OUTLINED __attribute__((noinline))
+#else
+#define VR_ROLLED
+#define VR_OUTLINED
+#endif
+
 struct VrUnionLane {
     VrLane L;                    /* ray, point, current node and its box (checked is not used) */
     uint32_t prev_mn, prev_mx;   /* range of the parent of the current node ([0, 255] above the root) */
@@ -184,6 +194,7 @@ template <class Fetch, class Stack, class Done, class Sink>
 VR_HD uint32_t vr_union_descend(VrUnionLane &U, const Fetch &fetch, Stack &stack, Done &done, Sink &sink, uint32_t max_trips)
 {
     VrLane &L = U.L;
+    VR_ROLLED
     for (uint32_t trip = 0; trip < max_trips; trip++) {
         const uint32_t n = fetch(L.g);
         const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
@@ -325,7 +336,7 @@ VR_HD void vr_union_leave(VrLane &L, Stack &stack, const VrUnionExit &x, bool &s
  * out of the box of level m: same state as the front's -> they get its escape helps, if any; another state -> they
  * leave the union walk (sink.except) and are marked done.  Walks the path again from the root, in registers. */
 template <class Fetch, class Done, class Sink>
-VR_HD void vr_union_resolve(VrUnionLane &U, const VrViewK &v, const Fetch &fetch, Done &done, Sink &sink, uint32_t depth_k,
+VR_OUTLINED VR_HD void vr_union_resolve(VrUnionLane &U, const VrViewK &v, const Fetch &fetch, Done &done, Sink &sink, uint32_t depth_k,
                             uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root_new)
 {
     VrLane T = U.L; /* the ray; box, node and point are set below */
