@@ -327,7 +327,9 @@ def main():
         if plan.rays and len(slots) == 1:
             si = capi.SweepInfo()
             for _ in range(args.settle):  # untimed, before the warm-up: the library tries its cuts of the iso range
-                step()
+                rr, rgb_k, stats_k, s_k = slots[0]
+                with torch.cuda.stream(s_k):  # the render alone: ranks settle after different numbers of launches,
+                    plan.render(rr, rgb_k, stats_k, C.c_void_p(s_k.cuda_stream))  # so nothing collective may ride along
                 torch.cuda.synchronize()
                 settle_steps += 1
                 if L.vr_sweep_info_read(r.handle, C.byref(si)) != capi.VR_OK or si.cut_settled:
