@@ -1308,17 +1308,18 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     WaveChunk chunk;
     uint32_t depth_k = 0, cell_before = 0, n_states = 0;
     bool alive = false, exhausted = false, popping = false, suspect = false;
-    /* the front of a lane is finished: on with the run it has kept, if any, else the lane is idle */
-    auto front_done = [&](bool &alive_, bool &popping_) {
-        if (sink.pend) {
-            vr_union_restart(U, stack, done, v, sink.pend_t, sink.pend_cell, sink.pend_runs);
-            sink.pend_shift();
-            popping_ = false;
-        } else {
-            alive_ = false;
-        }
-    };
-
+    /* the front of a lane is finished: on with the iso values it has kept, if any, else the lane is idle (a macro, not
+     * a lambda taking the two flags by reference: that kept them in scratch memory) */
+#define VR_FRONT_DONE()                                                                                     \
+    do {                                                                                                    \
+        if (sink.pend) {                                                                                    \
+            vr_union_restart(U, stack, done, v, sink.pend_t, sink.pend_cell, sink.pend_runs);               \
+            sink.pend_shift();                                                                              \
+            popping = false;                                                                                \
+        } else {                                                                                            \
+            alive = false;                                                                                  \
+        }                                                                                                   \
+    } while (0)
 
     for (;;) {
         /* ---- refill idle lanes from the ray queue ---- */
@@ -1352,7 +1353,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             if (!popping) go = vr_union_descend(U, fetch, stack, done, sink, kUnionDescendTrips);
             if (go == VR_GO_EXCLUDED) {
                 if (U.alive_lo > U.alive_hi) {
-                    front_done(alive, popping); /* every iso value of the front has hit */
+                    VR_FRONT_DONE(); /* every iso value of the front has hit */
                 } else {
                     depth_k = stack.depth(); cell_before = U.L.cell;
                     x = vr_union_move(U.L, v);
@@ -1368,7 +1369,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                         if (suspect) vr_union_resolve(U, v, fetch, done, sink, depth_k, cell_before, -1, t_new, 0u, false);
                         if (U.alive_lo <= U.alive_hi)
                             vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1); }, U.holes);
-                        front_done(alive, popping);
+                        VR_FRONT_DONE();
                     } else {
                         popping = true;
                     }
@@ -1380,7 +1381,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     if (suspect)
                         vr_union_resolve(U, v, fetch, done, sink, depth_k, cell_before, (int)stack.depth() - 1, U.L.t, U.L.cell, true);
                     vr_union_after_pop(U, fetch);
-                    if (U.alive_lo > U.alive_hi) front_done(alive, popping);
+                    if (U.alive_lo > U.alive_hi) VR_FRONT_DONE();
                 }
             }
         }
@@ -1445,6 +1446,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
         }
     }
 }
+
+#undef VR_FRONT_DONE
 
 /* The iso values that left the union walk: each is traced on its own from its own state (the checks and the MOVE of
  * the round that parked it are counted already, its escape helps of that MOVE come with the record). */

@@ -36,14 +36,13 @@
 
 #include "vr_trace_core.h"
 
-/* The lane code of a front is large (runs of iso values, both sides of a range, exact resolution): what is rare is kept
- * out of line and the level loop is not unrolled, so that the kernel's loop stays inside the instruction cache. */
+/* The lane code of a front is large (runs of iso values, both sides of a range, exact resolution): the level loop is
+ * not unrolled, so that the kernel's loop stays inside the instruction cache.  (Nothing is called out of line: a call
+ * makes the kernel use scratch memory, and with scratch the whole grid is no longer resident at once.) */
 #if defined(__clang__)
 #define VR_ROLLED _Pragma("unroll 1")
-#define VR_OUTLINED __attribute__((noinline))
 #else
 #define VR_ROLLED
-#define VR_OUTLINED
 #endif
 
 struct VrUnionLane {
@@ -336,7 +335,7 @@ VR_HD void vr_union_leave(VrLane &L, Stack &stack, const VrUnionExit &x, bool &s
  * out of the box of level m: same state as the front's -> they get its escape helps, if any; another state -> they
  * leave the union walk (sink.except) and are marked done.  Walks the path again from the root, in registers. */
 template <class Fetch, class Done, class Sink>
-VR_OUTLINED VR_HD void vr_union_resolve(VrUnionLane &U, const VrViewK &v, const Fetch &fetch, Done &done, Sink &sink, uint32_t depth_k,
+VR_HD void vr_union_resolve(VrUnionLane &U, const VrViewK &v, const Fetch &fetch, Done &done, Sink &sink, uint32_t depth_k,
                             uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root_new)
 {
     VrLane T = U.L; /* the ray; box, node and point are set below */
@@ -363,16 +362,17 @@ VR_OUTLINED VR_HD void vr_union_resolve(VrUnionLane &U, const VrViewK &v, const 
                 if (!same) { sink.except(r0, r1, own_t, own_cell, own.in_root, own.esc); marked = true; }
                 else if (own.esc) sink.esc(r0, r1, own.esc);
             };
-            /* runs are taken before anything is marked at this level: marking happens after both sides */
-            uint32_t r_lo[2] = { 1u, 1u }, r_hi[2] = { 0u, 0u };
-            if (mn > prev_mn) { r_lo[0] = prev_mn > U.alive_lo ? prev_mn : U.alive_lo; r_hi[0] = mn - 1u < U.alive_hi ? mn - 1u : U.alive_hi; }
-            if (mx < prev_mx) { r_lo[1] = mx + 1u > U.alive_lo ? mx + 1u : U.alive_lo; r_hi[1] = prev_mx < U.alive_hi ? prev_mx : U.alive_hi; }
-            for (int s = 0; s < 2; s++)
-                if (r_lo[s] <= r_hi[s]) vr_union_runs(done, r_lo[s], r_hi[s], each, U.holes);
+            /* runs are taken before anything is marked at this level: marking happens after both sides (scalars, not
+             * arrays: an indexed local array would live in scratch memory) */
+            uint32_t lo0 = 1u, hi0 = 0u, lo1 = 1u, hi1 = 0u;
+            if (mn > prev_mn) { lo0 = prev_mn > U.alive_lo ? prev_mn : U.alive_lo; hi0 = mn - 1u < U.alive_hi ? mn - 1u : U.alive_hi; }
+            if (mx < prev_mx) { lo1 = mx + 1u > U.alive_lo ? mx + 1u : U.alive_lo; hi1 = prev_mx < U.alive_hi ? prev_mx : U.alive_hi; }
+            if (lo0 <= hi0) vr_union_runs(done, lo0, hi0, each, U.holes);
+            if (lo1 <= hi1) vr_union_runs(done, lo1, hi1, each, U.holes);
             if (worked_out && !same) {
                 vr_union_need_bits(done, U);
-                for (int s = 0; s < 2; s++)
-                    if (r_lo[s] <= r_hi[s]) vr_union_mark(done, r_lo[s], r_hi[s]); /* already done ones stay done */
+                if (lo0 <= hi0) vr_union_mark(done, lo0, hi0); /* already done ones stay done */
+                if (lo1 <= hi1) vr_union_mark(done, lo1, hi1);
             }
         }
         if (m == depth_k) break;
