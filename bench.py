@@ -412,7 +412,8 @@ def main():
     if rank == 0:
         vol_name = {"skull": "Skull.vol", "c60": "C60.vol", "standin256": "256^3 stand-in", "gyroid1024": "1024^3 gyroid"}[args.volume]
         workload = "%s_%dx%d_iso%d-%d_sweep" % (args.volume, W, H, I0, I0 + IN - 1)
-        kernel_name = ("vr_k_render_wide" if args.kernel in (1, 2, 3) else "vr_k_sweep" if sweep_kernel else "vr_k_trace_wide") if wide else (
+        kernel_name = ("vr_k_render_wide" if args.kernel in (1, 2, 3) else "vr_k_sweep" if args.kernel == 5 else
+                       "vr_k_union" if sweep_kernel else "vr_k_trace_wide") if wide else (
             {0: "vr_k_union" if main_plan.iso_count >= 8 else "vr_k_trace", 4: "vr_k_trace", 5: "vr_k_sweep", 6: "vr_k_union"}.get(args.kernel, "vr_k_render"))
         alg_bytes = 4.0 * nodes_checked + 3.0 * main_plan.rays
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0

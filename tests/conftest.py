@@ -64,7 +64,7 @@ def emu_lib():
     import ctypes as C
     src = os.path.join(ROOT, "tests", "emu", "vr_emu.cpp")
     out = os.path.join(ROOT, "tests", "emu", "libvr_emu.so")
-    hdrs = [os.path.join(ROOT, "volumerenderer_amd", "csrc", h) for h in ("vr_trace_core.h", "vr_trace_wide.h", "vr_trace_union.h", "vr_trilerp.h")]
+    hdrs = [os.path.join(ROOT, "volumerenderer_amd", "csrc", h) for h in ("vr_trace_core.h", "vr_trace_wide.h", "vr_trace_union.h", "vr_trace_union_wide.h", "vr_trilerp.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(q) for q in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared",
                                "-o", out, src])

@@ -467,3 +467,135 @@ extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8
     if (counts_out) { counts_out[0] = n_reads; counts_out[1] = n_states; counts_out[2] = n_suspect; counts_out[3] = n_except; counts_out[4] = n_except_isos; }
     return 0;
 }
+
+/* ---- the union walk on wide trees (vr_trace_union_wide.h) ---- */
+#include "../../volumerenderer_amd/csrc/vr_trace_union_wide.h"
+namespace {
+struct HostUnionWideSink {
+    const VrViewK *k; const uint32_t *nodes; const VrWideLane *ray;
+    uint32_t iso_begin; uint64_t frame, pix;
+    uint8_t *gray; uint32_t *cell_flag; float *t_out; uint32_t *node; uint64_t *sums;
+    uint64_t n_except = 0, n_except_isos = 0;
+    bool pend = false; float pend_t = 0.0f; uint32_t pend_cell = 0; VrUnionRuns pend_runs = { 0u, 0u, 0u };
+    void finish(uint32_t iso, bool hit, float t, uint32_t cell, uint32_t idx)
+    {
+        const uint64_t at = (uint64_t)(iso - iso_begin) * frame + pix;
+        gray[at] = hit ? vr_shade(t) : 0;
+        cell_flag[at] = (hit ? cell : 0u) | ((hit ? 1u : 0u) << VR_WIDE_FLAG_SHIFT);
+        t_out[at] = t;
+        node[at] = hit ? idx : 0u;
+        sums[(iso - iso_begin) * 7 + (hit ? 1 : 2)]++;
+    }
+    void park(uint32_t r0, uint32_t r1, uint32_t checks)
+    {
+        for (uint32_t i = r0; i <= r1; i++) { sums[(i - iso_begin) * 7 + 0] += checks; sums[(i - iso_begin) * 7 + 5] += 1u; }
+    }
+    void hit(uint32_t r0, uint32_t r1, uint32_t checks, float t, uint32_t cell, uint32_t idx)
+    {
+        for (uint32_t i = r0; i <= r1; i++) { sums[(i - iso_begin) * 7 + 0] += checks; finish(i, true, t, cell, idx); }
+    }
+    void miss(uint32_t r0, uint32_t r1, float t) { for (uint32_t i = r0; i <= r1; i++) finish(i, false, t, 0, 0); }
+    void esc(uint32_t r0, uint32_t r1, uint32_t n) { for (uint32_t i = r0; i <= r1; i++) sums[(i - iso_begin) * 7 + 4] += n; }
+    void except(uint32_t r0, uint32_t r1, float t, uint32_t cell, bool in_root, uint32_t n_esc)
+    {
+        n_except++;
+        if (in_root && !pend) { pend = true; pend_t = t; pend_cell = cell; pend_runs.clear(); }
+        if (in_root && cell == pend_cell && vr_f32_bits(t) == vr_f32_bits(pend_t) && pend_runs.room()) {
+            n_except_isos += r1 - r0 + 1u;
+            esc(r0, r1, n_esc);
+            pend_runs.add(r0, r1);
+            return;
+        }
+        for (uint32_t iso = r0; iso <= r1; iso++) { /* what does not fit: iso value by iso value, as the second kernel does */
+            n_except_isos++;
+            sums[(iso - iso_begin) * 7 + 4] += n_esc;
+            if (!in_root) { finish(iso, false, t, 0, 0); continue; }
+            HostPath path;
+            VrWideLane A = *ray;
+            vr_wide_restart(A, *k, t, cell);
+            uint32_t moves = 0, e = 0;
+            bool hit = false;
+            for (;;) {
+                const uint32_t go = vr_wide_descend(A, *k, iso, HostFetch{ nodes }, path, VR_WIDE_MAX_DEPTH + 1u);
+                if (go == VR_GO_HIT) { hit = true; break; }
+                moves++;
+                if (!vr_wide_move(A, *k, e)) break;
+                while (!vr_wide_pop(A, path, 64u)) {}
+            }
+            sums[(iso - iso_begin) * 7 + 0] += A.checked; sums[(iso - iso_begin) * 7 + 4] += e; sums[(iso - iso_begin) * 7 + 5] += moves;
+            finish(iso, hit, A.t, A.c, A.idx);
+        }
+    }
+};
+} // namespace
+
+extern "C" int vr_emu_union_wide(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3], const float src[3],
+                                 const float forw[3], const float up[3], uint32_t width, uint32_t height, float viewport_width,
+                                 uint32_t iso_begin, uint32_t iso_count, uint32_t max_trips, uint8_t *gray, uint32_t *cell_flag,
+                                 float *t_out, uint32_t *node, uint64_t *sums /*[iso_count][7]*/, uint64_t *counts_out /*[5]*/)
+{
+    VrViewK k;
+    k.ox = src[0]; k.oy = src[1]; k.oz = src[2];
+    k.fx = forw[0]; k.fy = forw[1]; k.fz = forw[2];
+    k.ux = up[0]; k.uy = up[1]; k.uz = up[2];
+    k.rx = k.fy * k.uz - k.fz * k.uy;
+    k.ry = k.fz * k.ux - k.fx * k.uz;
+    k.rz = k.fx * k.uy - k.fy * k.ux;
+    k.pixel_size = viewport_width / (float)width;
+    k.half_w = (float)(width / 2);
+    k.half_h = (float)(height / 2);
+    k.width = width; k.height = height;
+    k.rdx = root_dim[0]; k.rdy = root_dim[1]; k.rdz = root_dim[2];
+    k.root_hi = 0;
+    k.n_slots = n_slots;
+    std::memset(sums, 0, (size_t)iso_count * 7 * sizeof(uint64_t));
+    const uint64_t frame = (uint64_t)width * height;
+    uint64_t n_reads = 0, n_states = 0, n_suspect = 0, n_except = 0, n_except_isos = 0;
+    for (uint32_t yi = 0; yi < height; yi++)
+        for (uint32_t xi = 0; xi < width; xi++) {
+            const uint64_t pix = (uint64_t)yi * width + xi;
+            VrRay ray = vr_make_ray(k, xi, yi);
+            if (ray.oob) {
+                for (uint32_t j = 0; j < iso_count; j++) {
+                    gray[j * frame + pix] = 0; cell_flag[j * frame + pix] = 2u << VR_WIDE_FLAG_SHIFT; t_out[j * frame + pix] = 0.0f;
+                    node[j * frame + pix] = 0; sums[j * 7 + 3]++;
+                }
+                continue;
+            }
+            HostPath path;
+            HostDone done;
+            VrUnionWideLane U;
+            vr_uw_begin(U, done, k, ray.dx, ray.dy, ray.dz, ray.t, iso_begin, iso_count);
+            const VrWideLane ray_lane = U.L;
+            HostUnionWideSink sink{ &k, nodes, &ray_lane, iso_begin, frame, pix, gray, cell_flag, t_out, node, sums };
+            const CountingFetch fetch{ nodes, &n_reads, 0u };
+            for (;;) {
+                while (U.alive_lo <= U.alive_hi) {
+                    const uint32_t go = vr_uw_descend(U, fetch, path, done, sink, max_trips);
+                    if (go == VR_GO_MORE) continue;
+                    if (U.alive_lo > U.alive_hi) break;
+                    n_states++;
+                    const uint32_t depth_k = U.L.d, cell_before = U.L.c;
+                    const VrUnionWideExit x = vr_uw_move(U.L, k);
+                    bool suspect = x.esc != 0u;
+                    if (!x.in_root) {
+                        const float t_new = U.L.t;
+                        vr_uw_leave(U.L, path, x, suspect);
+                        if (suspect) { n_suspect++; vr_uw_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false); }
+                        if (U.alive_lo <= U.alive_hi)
+                            vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1, t_new); }, U.holes);
+                        break;
+                    }
+                    while (!vr_uw_pop(U.L, path, max_trips, x, suspect)) {}
+                    if (suspect) { n_suspect++; vr_uw_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, (int)U.L.d - 1, U.L.t, U.L.c, true); }
+                    vr_uw_after_pop(U, HostFetch{ nodes });
+                }
+                if (!sink.pend) break;
+                sink.pend = false;
+                vr_uw_restart(U, done, k, sink.pend_t, sink.pend_cell, sink.pend_runs);
+            }
+            n_except += sink.n_except; n_except_isos += sink.n_except_isos;
+        }
+    if (counts_out) { counts_out[0] = n_reads; counts_out[1] = n_states; counts_out[2] = n_suspect; counts_out[3] = n_except; counts_out[4] = n_except_isos; }
+    return 0;
+}

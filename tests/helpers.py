@@ -103,6 +103,24 @@ def emu_union(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, max_trips
             "states": int(counts[1]), "suspect": int(counts[2]), "left_runs": int(counts[3]), "left_isos": int(counts[4])}
 
 
+def emu_union_wide(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, max_trips=5):
+    """The union walk on a wide tree (vr_trace_union_wide.h), on the CPU."""
+    gray = np.zeros((iso_count, h, w), np.uint8)
+    cf = np.zeros((iso_count, h, w), np.uint32)
+    tt = np.zeros((iso_count, h, w), np.float32)
+    nd = np.zeros((iso_count, h, w), np.uint32)
+    sums = np.zeros((iso_count, 7), np.uint64)
+    counts = np.zeros(5, np.uint64)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+    L.vr_emu_union_wide(C.c_void_p(nodes.ctypes.data), C.c_uint64(len(nodes)), (C.c_uint16 * 3)(*[int(x) for x in rd]), f3(pos),
+                        f3(f), f3(u), C.c_uint32(w), C.c_uint32(h), C.c_float(vp), C.c_uint32(iso_begin), C.c_uint32(iso_count),
+                        C.c_uint32(max_trips), C.c_void_p(gray.ctypes.data), C.c_void_p(cf.ctypes.data), C.c_void_p(tt.ctypes.data),
+                        C.c_void_p(nd.ctypes.data), C.c_void_p(sums.ctypes.data), C.c_void_p(counts.ctypes.data))
+    return {"gray": gray, "cell_flag": cf, "t": tt, "node": nd, "sums": sums, "node_reads": int(counts[0]),
+            "states": int(counts[1]), "suspect": int(counts[2]), "left_runs": int(counts[3]), "left_isos": int(counts[4])}
+
+
 def assert_same_render(got, ref, what=""):
     """Bit-exact comparison of every per-pixel output against the oracle."""
     assert (got["rgb"] == ref["rgb"]).all(), "%s: pixels differ (%d)" % (what, int((got["rgb"] != ref["rgb"]).sum()))

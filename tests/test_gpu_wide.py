@@ -161,6 +161,56 @@ def test_wide_sweep_kernel_every_iso_value_matches_wide_oracle(oracle):
     assert bool(torch.equal(res[0][0], res[1][0]))
 
 
+def test_wide_union_kernel_every_iso_value_matches_wide_oracle(oracle):
+    """ONE traversal per ray for the whole iso range on wide trees (vr_k_union with the wide lane code, the default for
+    sweeps without taps): frames and all 7 counters of every iso value against one oracle render each, ranges that do not
+    start at 0, and at a size where waves run full the frames and counters of the one-traversal-per-iso kernel."""
+    import torch
+    rng = np.random.default_rng(8)
+    for shape, kind, W, H, b, n in [((300, 24, 20), "noise", 72, 56, 0, 256), ((40, 520, 36), "smooth", 96, 64, 0, 256),
+                                    ((33, 20, 700), "sparse", 64, 48, 0, 256), ((300, 24, 20), "noise", 50, 40, 77, 9)]:
+        vox = random_volume(rng, shape, kind)
+        nodes, rd, _ = oracle.build_kdt(vox, wide=True)
+        pos, forw, up = oracle.main_camera(vox.shape)
+        with vr.Renderer(0) as r:
+            r.upload_kdt(vr.SlimKDT(nodes, rd, wide=True))
+            r.set_kernel(capi.KERNEL_UNION)
+            out = r.renderSweep(pos, forw, up, W, H, 2.5, b, n)
+        hits = 0
+        for j in range(0, n, 2 if n > 50 else 1):
+            ref = oracle.render(nodes, rd, pos, forw, up, W, H, 2.5, b + j, wide=True)
+            assert (out["rgb"][j] == ref["rgb"]).all(), "wide union kernel %s iso %d" % (shape, b + j)
+            st, o = out["stats"][j], ref["stats"]
+            assert (st["nodes_checked"], st["hit_count"], st["miss_count"], st["oob_count"], st["escape_help_events"], st["moves"],
+                    st["errors"]) == (o.nodes_checked, o.hit_count, o.miss_count, o.oob_count, o.escape_help_events, o.moves, 0), (shape, b + j)
+            hits += o.hit_count
+        assert hits > 500
+    vox = datasets.gyroid_noise(320)
+    pos, forw, up = oracle.main_camera(vox.shape)
+    L = capi.lib()
+    W = H = 768
+    v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+    with vr.Renderer(0) as r:
+        r.upload_volume(vr.Data(vox))
+        r.build_kdt("AlwaysCenter")
+        res = []
+        for variant in (capi.KERNEL_PIPELINE, capi.KERNEL_UNION, capi.KERNEL_DEFAULT):
+            r.set_kernel(variant)
+            d_rgb = torch.empty((64, H, W, 3), dtype=torch.uint8, device="cuda")
+            d_stats = torch.zeros((64, 7), dtype=torch.int64, device="cuda")
+            capi.check(L.vr_render_device(r.handle, C.byref(v), 100, 64, 0, H, d_rgb.data_ptr(), d_stats.data_ptr(), None, None),
+                       "vr_render_device")
+            capi.check(L.vr_sync(r.handle), "vr_sync")
+            res.append((d_rgb, d_stats.cpu().numpy()))
+        si = capi.SweepInfo()
+        capi.check(L.vr_sweep_info_read(r.handle, C.byref(si)), "vr_sweep_info_read")
+        assert 0 < si.walks <= si.items  # the default is the union kernel: one traversal per entering ray and block of iso values
+    for k in (1, 2):
+        assert (res[0][1] == res[k][1]).all(), np.argwhere(res[0][1] != res[k][1])[:8]
+        assert bool(torch.equal(res[0][0], res[k][0]))
+    assert int(res[0][1][:, 1].sum()) > 10 ** 6 and int(res[0][1][:, 6].sum()) == 0
+
+
 def test_wide_malformed_tree_is_refused_at_upload():
     rng = np.random.default_rng(5)
     nodes = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)

@@ -7,7 +7,7 @@ apply, and tie the product's wide lane code (vr_trace_wide.h, run on the CPU) to
 import numpy as np
 import pytest
 
-from helpers import assert_same_render, emu_wide, random_volume
+from helpers import assert_same_render, emu_union_wide, emu_wide, random_volume
 
 
 def narrow_to_wide_words(nodes):
@@ -109,3 +109,25 @@ def test_wide_tree_validation(oracle):
     junk = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
     assert check_wide(junk, [300, 200, 100])[0] == capi.VR_ETREE
     assert check_wide(nodes, [1024, 8, 6])[0] == capi.VR_EARG
+
+
+@pytest.mark.parametrize("shape,kind", [((300, 9, 11), "noise"), ((10, 280, 12), "smooth"), ((12, 10, 270), "sparse")])
+def test_wide_union_walk_equals_one_render_per_iso(oracle, emu_lib, shape, kind):
+    """ONE traversal per ray for a whole iso range on wide trees: every per-iso output and counter equals the wide oracle's
+    separate render of that iso value."""
+    rng = np.random.default_rng(sum(shape) + 1)
+    vox = random_volume(rng, shape, kind)
+    nodes, rd, st = oracle.build_kdt(vox, wide=True)
+    for cam, vp in [((-30.0, -300.0, -30.0), 0.2), ((float(shape[0]) + 40.0, 20.0, 10.0), 3.0), ((8.0, 8.0, -320.0), 0.2)]:
+        pos, forw, up = oracle.main_camera(shape, cam)
+        for b, n, trips in [(0, 256, 5), (40, 100, 1), (250, 6, 64)]:
+            got = emu_union_wide(emu_lib, nodes, rd, pos, forw, up, 32, 24, vp, b, n, max_trips=trips)
+            for j in range(0, n, 1 if n < 50 else 7):
+                ref = oracle.render(nodes, rd, pos, forw, up, 32, 24, vp, b + j, wide=True)
+                hit = (ref["cell_flag"] >> 30) == 1
+                assert (got["gray"][j] == ref["rgb"][..., 0]).all(), (shape, cam, b, j)
+                assert (got["cell_flag"][j] == ref["cell_flag"]).all() and (got["node"][j] == ref["node"]).all(), (shape, cam, b, j)
+                assert (got["t"][j].view(np.uint32)[hit] == ref["t"].view(np.uint32)[hit]).all(), (shape, cam, b, j)
+                s = ref["stats"]
+                assert tuple(int(x) for x in got["sums"][j][:6]) == (s.nodes_checked, s.hit_count, s.miss_count, s.oob_count,
+                                                                     s.escape_help_events, s.moves), (shape, cam, b, j)

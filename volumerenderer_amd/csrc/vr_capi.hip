@@ -283,7 +283,8 @@ int vr_upload_kdt_wide(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const
         if (root_dim[a] == 0 || root_dim[a] >= VR_WIDE_MAX_RES) return VR_EARG;
     /* validate on the host before anything reaches the device: the kernels walk the array without checks */
     uint32_t max_depth = 0;
-    const int rc = vr_host_check_kdt_wide(nodes, n_slots, root_dim, &max_depth, nullptr);
+    bool nested = false;
+    const int rc = vr_host_check_kdt_wide_nested(nodes, n_slots, root_dim, &max_depth, nullptr, &nested);
     if (rc != VR_OK) return rc;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess && c->d_nodes) { e = hipFree(c->d_nodes); c->d_nodes = nullptr; }
@@ -297,6 +298,7 @@ int vr_upload_kdt_wide(vr_ctx *c, const uint32_t *nodes, uint64_t n_slots, const
     c->max_depth = max_depth;
     for (int a = 0; a < 3; a++) c->root_dim[a] = root_dim[a];
     c->wide = true;
+    c->ranges_nested = nested;
     return VR_OK;
 }
 
@@ -325,6 +327,7 @@ int vr_build_kdt(vr_ctx *c, int heuristic, vr_build_stats *stats_out)
         c->max_depth = depth;
         for (int a = 0; a < 3; a++) c->root_dim[a] = c->res[a] - 1u;
         c->wide = true;
+        c->ranges_nested = true; /* a node's range is the union of its children's */
         if (stats_out) {
             const uint64_t cells = (uint64_t)(c->res[0] - 1u) * (c->res[1] - 1u) * (c->res[2] - 1u);
             stats_out->non_center_partition_count = 0;
@@ -559,7 +562,7 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
     }
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
     /* one traversal per ray for the whole iso range: nothing to cut, nothing to tune (same rule as vr_launch_render) */
-    const bool union_kernel = !c->wide && c->ranges_nested && !any_tap &&
+    const bool union_kernel = c->ranges_nested && !any_tap &&
                               (variant == VR_KERNEL_UNION || (variant == VR_KERNEL_DEFAULT && iso_count >= VR_UNION_MIN_ISOS));
     const bool sweep_kernel = !union_kernel && (variant == VR_KERNEL_SWEEP || variant == VR_KERNEL_UNION ||
                                                 (variant == VR_KERNEL_DEFAULT && iso_count >= 8u));
@@ -570,7 +573,7 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         sweep_tune_next(c, view, iso_begin, iso_count, row_begin, row_end - row_begin, band_rows, union_kernel, &ipl, &seq);
     if (c->wide)
         VR_HIP(vr_launch_render_wide(variant, s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
-                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq));
+                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq, c->ranges_nested));
     else
         VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
                                 row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq,

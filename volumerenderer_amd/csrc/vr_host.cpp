@@ -439,18 +439,29 @@ bool vr_host_ranges_nested(const uint32_t *prepared, uint64_t prepared_words)
     return true;
 }
 
+int vr_host_check_kdt_wide_nested(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3], uint32_t *max_depth_out,
+                                  uint64_t *n_nodes_out, bool *nested_out);
+
 int vr_host_check_kdt_wide(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3], uint32_t *max_depth_out,
                            uint64_t *n_nodes_out)
+{
+    return vr_host_check_kdt_wide_nested(nodes, n_slots, root_dim, max_depth_out, n_nodes_out, nullptr);
+}
+
+/* the same walk; *nested_out (if given) = every reachable node's density range lies inside its parent's */
+int vr_host_check_kdt_wide_nested(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3], uint32_t *max_depth_out,
+                                  uint64_t *n_nodes_out, bool *nested_out)
 {
     if (!nodes || !n_slots || !root_dim) return VR_EARG;
     if (n_slots > ((uint64_t)1 << 31)) return VR_EARG;
     for (int a = 0; a < 3; a++)
         if (root_dim[a] == 0 || root_dim[a] > 1023) return VR_EARG;
-    struct Item { uint64_t idx; uint16_t lo[3], hi[3]; uint32_t depth; };
+    struct Item { uint64_t idx; uint16_t lo[3], hi[3]; uint32_t depth; uint8_t pmn, pmx; };
     std::vector<Item> todo;
     todo.reserve(128);
     Item root;
-    root.idx = 0; root.depth = 0;
+    root.idx = 0; root.depth = 0; root.pmn = 0; root.pmx = 255;
+    bool nested = true;
     for (int a = 0; a < 3; a++) { root.lo[a] = 0; root.hi[a] = root_dim[a]; }
     todo.push_back(root);
     uint32_t max_depth = 0;
@@ -463,6 +474,7 @@ int vr_host_check_kdt_wide(const uint32_t *nodes, uint64_t n_slots, const uint16
         const uint32_t axis = (n >> 28) & 3u, part = (n >> 16) & 0xfffu;
         count++;
         if (it.depth > max_depth) max_depth = it.depth;
+        if ((n & 0xffu) < it.pmn || ((n >> 8) & 0xffu) > it.pmx) nested = false;
         const uint32_t size = (uint32_t)(it.hi[0] - it.lo[0]) * (uint32_t)(it.hi[1] - it.lo[1]) * (uint32_t)(it.hi[2] - it.lo[2]);
         if (size == 1) continue; /* leaf cell: src/raytrace.zig:178 */
         /* an inner node must split strictly inside its box (see vr_host_prepare_kdt) */
@@ -470,6 +482,7 @@ int vr_host_check_kdt_wide(const uint32_t *nodes, uint64_t n_slots, const uint16
         Item l = it, r = it;
         l.idx = 2 * it.idx + 1; r.idx = 2 * it.idx + 2;
         l.depth = r.depth = it.depth + 1;
+        l.pmn = r.pmn = (uint8_t)(n & 0xffu); l.pmx = r.pmx = (uint8_t)((n >> 8) & 0xffu);
         l.hi[axis] = (uint16_t)part;
         r.lo[axis] = (uint16_t)part;
         todo.push_back(r);
@@ -477,6 +490,7 @@ int vr_host_check_kdt_wide(const uint32_t *nodes, uint64_t n_slots, const uint16
     }
     if (max_depth_out) *max_depth_out = max_depth;
     if (n_nodes_out) *n_nodes_out = count;
+    if (nested_out) *nested_out = nested;
     return VR_OK;
 }
 

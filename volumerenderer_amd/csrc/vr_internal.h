@@ -43,6 +43,8 @@ enum {
 
 /* Are the density ranges of a prepared tree nested along every path (vr_host.cpp)? */
 extern "C" bool vr_host_ranges_nested(const uint32_t *prepared, uint64_t prepared_words);
+extern "C" int vr_host_check_kdt_wide_nested(const uint32_t *nodes, uint64_t n_slots, const uint16_t root_dim[3], uint32_t *max_depth_out,
+                                             uint64_t *n_nodes_out, bool *nested_out);
 
 /* Device scratch the pipeline variant needs for one call (ray list, tile offsets, queue heads). */
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count);
@@ -92,7 +94,8 @@ hipError_t vr_build_span_tree(hipStream_t stream, const uint8_t *d_vox, uint32_t
 hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes,
                                  uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
-                                 hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq);
+                                 hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq,
+                                 bool ranges_nested);
 
 
 /* One ray with the literal loop, every iteration recorded (vr_refine.hip): d_steps holds cap records, d_report one. */

@@ -32,6 +32,7 @@
 #include "vr_internal.h"
 #include "vr_trace_wide.h"
 #include "vr_trace_union.h"
+#include "vr_trace_union_wide.h"
 
 namespace {
 
@@ -1260,6 +1261,64 @@ struct UnionSink {
     }
 };
 
+/* the union kernel's lane code for the two tree formats */
+struct UnionNarrow {
+    typedef VrUnionLane ULane;
+    typedef LdsStack<kTraceThreads> Store;
+    typedef TopFetch Fetch;
+    typedef VrUnionExit Exit;
+    typedef SweepNarrow Ray;
+    __device__ static __forceinline__ Store store(uint32_t *) { return Store(); }
+    __device__ static __forceinline__ Fetch fetch(const uint32_t *nodes, const uint32_t *s_top, uint32_t n_top, uint64_t n_slots) { return TopFetch(nodes, s_top, n_top, n_slots); }
+    template <class Done>
+    __device__ static __forceinline__ void begin(ULane &U, Store &st, Done &done, const VrViewK &v, const float4 &r, uint32_t b, uint32_t n) { vr_union_begin(U, st, done, v, r.x, r.y, r.z, r.w, b, n); }
+    template <class Done>
+    __device__ static __forceinline__ void restart(ULane &U, Store &st, Done &done, const VrViewK &v, float t, uint32_t cell, const VrUnionRuns &runs) { vr_union_restart(U, st, done, v, t, cell, runs); }
+    template <class Done, class Sink>
+    __device__ static __forceinline__ uint32_t descend(ULane &U, const Fetch &f, Store &st, Done &done, Sink &sink) { return vr_union_descend(U, f, st, done, sink, kUnionDescendTrips); }
+    __device__ static __forceinline__ uint32_t depth(const ULane &, const Store &st) { return st.depth(); }
+    __device__ static __forceinline__ uint32_t cell(const ULane &U) { return U.L.cell; }
+    __device__ static __forceinline__ Exit move(ULane &U, const VrViewK &v) { return vr_union_move(U.L, v); }
+    __device__ static __forceinline__ bool pop(ULane &U, Store &st, const Exit &x, bool &suspect) { return vr_union_pop(U.L, st, kUnionPopTrips, x, suspect); }
+    __device__ static __forceinline__ void leave(ULane &U, Store &st, const Exit &x, bool &suspect) { vr_union_leave(U.L, st, x, suspect); }
+    template <class Done, class Sink>
+    __device__ static __forceinline__ void resolve(ULane &U, const VrViewK &v, const Fetch &f, Done &done, Sink &sink, uint32_t depth_k,
+                                                   uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root)
+    {
+        vr_union_resolve(U, v, f, done, sink, depth_k, cell_before, a_level, t_new, cell_new, in_root);
+    }
+    __device__ static __forceinline__ void after_pop(ULane &U, const Fetch &f) { vr_union_after_pop(U, f); }
+};
+
+struct UnionWide {
+    typedef VrUnionWideLane ULane;
+    typedef LdsPath<kTraceThreads> Store;
+    typedef WideFetch Fetch;
+    typedef VrUnionWideExit Exit;
+    typedef SweepWide Ray;
+    __device__ static __forceinline__ Store store(uint32_t *s_dyn) { return Store{ s_dyn + threadIdx.x }; }
+    __device__ static __forceinline__ Fetch fetch(const uint32_t *nodes, const uint32_t *, uint32_t, uint64_t n_slots) { return WideFetch{ nodes, n_slots >= 2u ? (uint32_t)(n_slots - 2u) : 0u }; }
+    template <class Done>
+    __device__ static __forceinline__ void begin(ULane &U, Store &, Done &done, const VrViewK &v, const float4 &r, uint32_t b, uint32_t n) { vr_uw_begin(U, done, v, r.x, r.y, r.z, r.w, b, n); }
+    template <class Done>
+    __device__ static __forceinline__ void restart(ULane &U, Store &, Done &done, const VrViewK &v, float t, uint32_t cell, const VrUnionRuns &runs) { vr_uw_restart(U, done, v, t, cell, runs); }
+    template <class Done, class Sink>
+    __device__ static __forceinline__ uint32_t descend(ULane &U, const Fetch &f, Store &st, Done &done, Sink &sink) { return vr_uw_descend(U, f, st, done, sink, kUnionDescendTrips); }
+    __device__ static __forceinline__ uint32_t depth(const ULane &U, const Store &) { return U.L.d; }
+    __device__ static __forceinline__ uint32_t cell(const ULane &U) { return U.L.c; }
+    __device__ static __forceinline__ Exit move(ULane &U, const VrViewK &v) { return vr_uw_move(U.L, v); }
+    __device__ static __forceinline__ bool pop(ULane &U, Store &st, const Exit &x, bool &suspect) { return vr_uw_pop(U.L, st, kUnionPopTrips, x, suspect); }
+    __device__ static __forceinline__ void leave(ULane &U, Store &st, const Exit &x, bool &suspect) { vr_uw_leave(U.L, st, x, suspect); }
+    template <class Done, class Sink>
+    __device__ static __forceinline__ void resolve(ULane &U, const VrViewK &v, const Fetch &f, Done &done, Sink &sink, uint32_t depth_k,
+                                                   uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root)
+    {
+        vr_uw_resolve(U, v, f, done, sink, depth_k, cell_before, a_level, t_new, cell_new, in_root);
+    }
+    __device__ static __forceinline__ void after_pop(ULane &U, const Fetch &f) { vr_uw_after_pop(U, f); }
+};
+
+template <class UOPS>
 __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top, uint32_t stack_rows, const float4 *__restrict__ ray_dt,
     const uint32_t *__restrict__ ray_pix, const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ head, uint32_t iso_begin,
@@ -1276,9 +1335,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     for (uint32_t i = threadIdx.x; i < sweep_stat_words(iso_count); i += kTraceThreads) s_dyn[stack_rows * kTraceThreads + i] = 0u;
     for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_top[i] = nodes[i];
     __syncthreads();
-    LdsStack<kTraceThreads> stack;
+    typename UOPS::Store stack = UOPS::store(s_dyn);
     LdsDone<kTraceThreads> done{ s_done + threadIdx.x };
-    const TopFetch fetch(nodes, s_top, n_top, v.n_slots);
+    const typename UOPS::Fetch fetch = UOPS::fetch(nodes, s_top, n_top, v.n_slots);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_active = *n_active_ptr;
@@ -1302,9 +1361,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     sink.except_count = (uint32_t *)n_active_ptr + 32; sink.except_list = except_list; sink.except_cap = except_cap;
     sink.pend = false; sink.pend_t = 0.0f; sink.pend_cell = 0; sink.pend_runs.clear();
     sink.pend2 = false; sink.pend2_t = 0.0f; sink.pend2_cell = 0; sink.pend2_runs.clear();
-    VrUnionLane U;
-    VrUnionExit x;
-    x.ex = 0; x.sh = 0; x.esc = 0; x.in_root = false;
+    typename UOPS::ULane U;
+    typename UOPS::Exit x = {};
     WaveChunk chunk;
     uint32_t depth_k = 0, cell_before = 0, n_states = 0;
     bool alive = false, exhausted = false, popping = false, suspect = false;
@@ -1313,7 +1371,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
 #define VR_FRONT_DONE()                                                                                     \
     do {                                                                                                    \
         if (sink.pend) {                                                                                    \
-            vr_union_restart(U, stack, done, v, sink.pend_t, sink.pend_cell, sink.pend_runs);               \
+            UOPS::restart(U, stack, done, v, sink.pend_t, sink.pend_cell, sink.pend_runs);                  \
             sink.pend_shift();                                                                              \
             popping = false;                                                                                \
         } else {                                                                                            \
@@ -1336,7 +1394,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     sink.pix = ray_pix[ray];
                     sink.ray = ray;
                     const uint32_t b0 = blk * block_isos, b1 = b0 + block_isos < iso_count ? b0 + block_isos : iso_count;
-                    vr_union_begin(U, stack, done, v, r.x, r.y, r.z, r.w, iso_begin + b0, b1 - b0);
+                    UOPS::begin(U, stack, done, v, r, iso_begin + b0, b1 - b0);
                     alive = true; popping = false; n_states = 0;
                     n_walks++;
                 }
@@ -1350,13 +1408,13 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
         }
         if (alive) {
             uint32_t go = VR_GO_MORE;
-            if (!popping) go = vr_union_descend(U, fetch, stack, done, sink, kUnionDescendTrips);
+            if (!popping) go = UOPS::descend(U, fetch, stack, done, sink);
             if (go == VR_GO_EXCLUDED) {
                 if (U.alive_lo > U.alive_hi) {
                     VR_FRONT_DONE(); /* every iso value of the front has hit */
                 } else {
-                    depth_k = stack.depth(); cell_before = U.L.cell;
-                    x = vr_union_move(U.L, v);
+                    depth_k = UOPS::depth(U, stack); cell_before = UOPS::cell(U);
+                    x = UOPS::move(U, v);
                     suspect = x.esc != 0u;
                     if (++n_states > kUnionMaxStates) { /* safety valve: the iso values left are reported as errors */
                         vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); }, U.holes);
@@ -1365,8 +1423,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     } else if (!x.in_root) {
                         /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
                         const float t_new = U.L.t;
-                        vr_union_leave(U.L, stack, x, suspect);
-                        if (suspect) vr_union_resolve(U, v, fetch, done, sink, depth_k, cell_before, -1, t_new, 0u, false);
+                        UOPS::leave(U, stack, x, suspect);
+                        if (suspect) UOPS::resolve(U, v, fetch, done, sink, depth_k, cell_before, -1, t_new, 0u, false);
                         if (U.alive_lo <= U.alive_hi)
                             vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1); }, U.holes);
                         VR_FRONT_DONE();
@@ -1376,11 +1434,11 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                 }
             }
             if (popping && alive) {
-                if (vr_union_pop(U.L, stack, kUnionPopTrips, x, suspect)) {
+                if (UOPS::pop(U, stack, x, suspect)) {
                     popping = false;
                     if (suspect)
-                        vr_union_resolve(U, v, fetch, done, sink, depth_k, cell_before, (int)stack.depth() - 1, U.L.t, U.L.cell, true);
-                    vr_union_after_pop(U, fetch);
+                        UOPS::resolve(U, v, fetch, done, sink, depth_k, cell_before, (int)UOPS::depth(U, stack) - 1, U.L.t, UOPS::cell(U), true);
+                    UOPS::after_pop(U, fetch);
                     if (U.alive_lo > U.alive_hi) VR_FRONT_DONE();
                 }
             }
@@ -1399,11 +1457,11 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             g_runs.w23 = (uint32_t)__builtin_amdgcn_readlane((int)sink.pend_runs.w23, giver);
             const uint32_t g_pix = (uint32_t)__builtin_amdgcn_readlane((int)sink.pix, giver);
             const uint32_t g_ray = (uint32_t)__builtin_amdgcn_readlane((int)sink.ray, giver);
-            SweepNarrow::adopt(U.L, giver, lane == taker);
+            UOPS::Ray::adopt(U.L, giver, lane == taker);
             if (lane == giver) sink.pend_shift();
             if (lane == taker) {
                 sink.pix = g_pix; sink.ray = g_ray;
-                vr_union_restart(U, stack, done, v, g_t, g_cell, g_runs);
+                UOPS::restart(U, stack, done, v, g_t, g_cell, g_runs);
                 alive = true; popping = false; n_states = 0;
             }
         }
@@ -1482,6 +1540,57 @@ __global__ __launch_bounds__(64) void vr_k_union_fix(VrViewK v, const uint32_t *
                     if (A.checked > VR_MAX_CHECKED) { err = 1; break; }
                     if (!vr_lane_move(A, v, esc)) break;
                     while (!vr_lane_pop(A, st, 64u)) {}
+                }
+            }
+            if (stats) {
+                vr_render_stats *s = stats + (iso - iso_begin);
+                add_stat(&s->nodes_checked, A.checked);
+                add_stat(hit ? &s->hit_count : &s->miss_count, 1ull);
+                add_stat(&s->moves, moves);
+                add_stat(&s->escape_help_events, esc);
+                add_stat(&s->errors, err);
+            }
+            if (hit) {
+                const uint8_t g = vr_shade(A.t);
+                uint8_t *p = rgb + ((uint64_t)(iso - iso_begin) * frame_pixels + pix) * 3u;
+                p[0] = g; p[1] = g; p[2] = g;
+            }
+        }
+    }
+}
+
+/* vr_k_union_fix for wide trees */
+__global__ __launch_bounds__(64) void vr_k_union_fix_wide(VrViewK v, const uint32_t *__restrict__ nodes, const float4 *__restrict__ ray_dt,
+                                                          const uint32_t *__restrict__ ray_pix, const uint32_t *__restrict__ n_active_ptr,
+                                                          const VrUnionRecord *__restrict__ list, uint32_t cap, uint32_t iso_begin,
+                                                          uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats)
+{
+    __shared__ uint32_t s_path[VR_WIDE_MAX_DEPTH * 64u];
+    uint32_t count = n_active_ptr[32];
+    count = count < cap ? count : cap;
+    LdsPath<64u> path{ s_path + threadIdx.x };
+    const WideFetch fetch{ nodes, 0u };
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const VrUnionRecord rec = list[i];
+        const float4 r = ray_dt[rec.ray];
+        const uint32_t pix = ray_pix[rec.ray];
+        const uint32_t r0 = rec.run & 0xffu, r1 = (rec.run >> 8) & 0xffu;
+        const bool in_root = (rec.run >> 16) & 1u;
+        VrWideLane A;
+        vr_wide_begin(A, v, r.x, r.y, r.z, r.w);
+        for (uint32_t iso = r0 + threadIdx.x; iso <= r1; iso += 64u) {
+            uint32_t moves = 0, esc = rec.esc, err = 0;
+            bool hit = false;
+            A.checked = 0;
+            if (in_root) {
+                vr_wide_restart(A, v, __builtin_bit_cast(float, rec.t_bits), rec.cell);
+                for (;;) {
+                    const uint32_t go = vr_wide_descend(A, v, iso, fetch, path, VR_WIDE_MAX_DEPTH + 1u);
+                    if (go == VR_GO_HIT) { hit = true; break; }
+                    moves++;
+                    if (A.checked > VR_MAX_CHECKED) { err = 1; break; }
+                    if (!vr_wide_move(A, v, esc)) break;
+                    while (!vr_wide_pop(A, path, 64u)) {}
                 }
             }
             if (stats) {
@@ -1781,7 +1890,7 @@ hipError_t vr_device_setup(int device)
                           (const void *)vr_k_sweep<false, SweepNarrow>, (const void *)vr_k_sweep<true, SweepNarrow>,
                           (const void *)vr_k_sweep<false, SweepWide>,   (const void *)vr_k_sweep<true, SweepWide>,
                           (const void *)vr_k_trace_wide<false>, (const void *)vr_k_trace_wide<true>,
-                          (const void *)vr_k_union };
+                          (const void *)vr_k_union<UnionNarrow>, (const void *)vr_k_union<UnionWide> };
     for (const void *fn : fns)
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u))) != hipSuccess) return e;
     void *p = nullptr;
@@ -1925,7 +2034,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                            (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
                            (void *)&launch_seq };
     void **args = use_union ? args_union : (sweep ? args_sweep : args_trace);
-    const void *fn = use_union ? (const void *)vr_k_union
+    const void *fn = use_union ? (const void *)vr_k_union<UnionNarrow>
                    : sweep ? (any_tap ? (const void *)vr_k_sweep<true, SweepNarrow> : (const void *)vr_k_sweep<false, SweepNarrow>)
                            : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
 
@@ -2003,7 +2112,8 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
 hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes,
                                  uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
-                                 hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq)
+                                 hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq,
+                                 bool ranges_nested)
 {
     const uint32_t n_rows = row_end - row_begin;
     hipError_t e = hipSuccess;
@@ -2018,12 +2128,33 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         return e;
     }
     /* a block of iso values: the sweep kernel with the wide lane code (traversals shared between iso values) */
-    const bool sweep = variant == VR_KERNEL_SWEEP || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u);
+    const bool sweep = variant == VR_KERNEL_SWEEP || variant == VR_KERNEL_UNION || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u);
     Prepass pp;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
                             VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp)) != hipSuccess)
         return e;
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
+    /* one traversal per ray for the whole iso range, under the same conditions as on narrow trees (vr_launch_render) */
+    if (sweep && variant != VR_KERNEL_SWEEP && !any_tap && ranges_nested) {
+        const uint32_t n_top = 0u, stack_rows = VR_WIDE_MAX_DEPTH;
+        const size_t lds = ((size_t)(stack_rows + 8u) * kTraceThreads + sweep_stat_words(iso_count)) * sizeof(uint32_t);
+        if (lds > 160u * 1024u) return hipErrorInvalidValue;
+        const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
+        const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
+        VrUnionRecord *except_list = (VrUnionRecord *)((char *)pp.heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
+        uint32_t except_cap = VR_UNION_EXCEPT_CAP;
+        void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&stack_rows, (void *)&pp.ray_dt, (void *)&pp.ray_pix,
+                         (void *)&pp.n_active, (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
+                         (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
+                         (void *)&launch_seq };
+        if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
+        if ((e = hipLaunchKernel((const void *)vr_k_union<UnionWide>, dim3(blocks), dim3(kTraceThreads), args, lds, stream)) != hipSuccess) return e;
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(vr_k_union_fix_wide, dim3(2048), dim3(64), 0, stream, view, d_nodes, pp.ray_dt, pp.ray_pix, pp.n_active,
+                           except_list, except_cap, iso_begin, frame_pixels, d_rgb, d_stats);
+        return hipGetLastError();
+    }
     if (sweep) {
         const uint32_t n_top = 0u, stack_rows = VR_WIDE_MAX_DEPTH;
         const size_t lds = ((size_t)stack_rows * kTraceThreads + sweep_stat_words(iso_count)) * sizeof(uint32_t);

@@ -97,8 +97,8 @@ VR_HD void vr_union_mark(Done &done, uint32_t r0, uint32_t r1)
 }
 
 /* is any iso value in [mn, mx] not done? */
-template <class Done>
-VR_HD bool vr_union_any(const Done &done, const VrUnionLane &U, uint32_t mn, uint32_t mx)
+template <class Done, class ULane>
+VR_HD bool vr_union_any(const Done &done, const ULane &U, uint32_t mn, uint32_t mx)
 {
     if (U.alive_lo > U.alive_hi || mx < U.alive_lo || mn > U.alive_hi) return false;
     if (!U.holes || (mn <= U.alive_lo && U.alive_lo <= mx) || (mn <= U.alive_hi && U.alive_hi <= mx)) return true;
@@ -112,8 +112,8 @@ VR_HD bool vr_union_any(const Done &done, const VrUnionLane &U, uint32_t mn, uin
 }
 
 /* The first done iso value strictly inside the alive range is about to be marked: from here on the bits count. */
-template <class Done>
-VR_HD void vr_union_need_bits(Done &done, VrUnionLane &U)
+template <class Done, class ULane>
+VR_HD void vr_union_need_bits(Done &done, ULane &U)
 {
     if (U.holes) return;
     for (uint32_t w = 0; w < 8u; w++) done.clear(w);
@@ -121,8 +121,8 @@ VR_HD void vr_union_need_bits(Done &done, VrUnionLane &U)
 }
 
 /* after marking: pulls alive_lo / alive_hi in to the nearest iso values that are not done */
-template <class Done>
-VR_HD void vr_union_shrink(const Done &done, VrUnionLane &U)
+template <class Done, class ULane>
+VR_HD void vr_union_shrink(const Done &done, ULane &U)
 {
     while (U.alive_lo <= U.alive_hi) {
         const uint32_t w = U.alive_lo >> 5, bits = ~done.word(w) >> (U.alive_lo & 31u);
@@ -166,10 +166,10 @@ struct VrUnionRuns {
 
 /* A new front for the runs `runs` of iso values of the same ray from the state (t, cell): what iso values that left the
  * union walk carry on with (their own MOVE has been made and counted; the reference returns to the root next). */
-template <class Stack, class Done>
-VR_HD void vr_union_restart(VrUnionLane &U, Stack &stack, Done &done, const VrViewK &v, float t, uint32_t cell, const VrUnionRuns &runs)
+/* the iso values of a front that starts at the root: the runs `runs`, everything else done */
+template <class Done, class ULane>
+VR_HD void vr_union_set_runs(ULane &U, Done &done, const VrUnionRuns &runs)
 {
-    vr_lane_restart(U.L, stack, v, t, cell);
     U.prev_mn = 0u; U.prev_mx = 255u;
     U.alive_lo = 255u; U.alive_hi = 0u;
     U.holes = runs.n > 1u;
@@ -184,6 +184,13 @@ VR_HD void vr_union_restart(VrUnionLane &U, Stack &stack, Done &done, const VrVi
             done.unset(w, (0xffffffffu >> (31u - b)) & (0xffffffffu << a));
         }
     }
+}
+
+template <class Stack, class Done>
+VR_HD void vr_union_restart(VrUnionLane &U, Stack &stack, Done &done, const VrViewK &v, float t, uint32_t cell, const VrUnionRuns &runs)
+{
+    vr_lane_restart(U.L, stack, v, t, cell);
+    vr_union_set_runs(U, done, runs);
 }
 
 /* Goes down from the current node while an iso value that is not done holds, at most max_trips levels.  Returns
