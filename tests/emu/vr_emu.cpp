@@ -445,18 +445,22 @@ extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8
                     n_states++;
                     const uint32_t depth_k = st.depth(), cell_before = U.L.cell;
                     const VrUnionExit x = vr_union_move(U.L, k);
-                    bool suspect = x.esc != 0u;
+                    bool suspect = false;
                     if (!x.in_root) {
                         const float t_new = U.L.t;
                         vr_union_leave(U.L, st, x, suspect);
-                        if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false); }
+                        if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false, VrUnionFrom{ 1u, 0u, k.root_hi }); }
+                        else vr_union_credit_esc(done, U, sink, 0u, 255u, x.esc);
                         if (U.alive_lo <= U.alive_hi)
                             vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1, t_new); }, U.holes);
                         break;
                     }
-                    while (!vr_union_pop(U.L, st, max_trips, x, suspect)) {}
-                    if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, (int)st.depth() - 1, U.L.t, U.L.cell, true); }
+                    VrUnionFrom from = { 1u, 0u, k.root_hi };
+                    while (!vr_union_pop(U.L, st, max_trips, x, suspect, from)) {}
+                    if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, (int)st.depth() - 1, U.L.t, U.L.cell, true, from); }
+                    const bool credit = !suspect;
                     vr_union_after_pop(U, HostFetch{ nodes });
+                    if (credit) vr_union_credit_esc(done, U, sink, U.prev_mn, U.prev_mx, x.esc);
                 }
                 if (!sink.pend) break;
                 sink.pend = false;
@@ -577,18 +581,22 @@ extern "C" int vr_emu_union_wide(const uint32_t *nodes, uint64_t n_slots, const 
                     n_states++;
                     const uint32_t depth_k = U.L.d, cell_before = U.L.c;
                     const VrUnionWideExit x = vr_uw_move(U.L, k);
-                    bool suspect = x.esc != 0u;
+                    bool suspect = false;
                     if (!x.in_root) {
                         const float t_new = U.L.t;
                         vr_uw_leave(U.L, path, x, suspect);
-                        if (suspect) { n_suspect++; vr_uw_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false); }
+                        if (suspect) { n_suspect++; vr_uw_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false, VrUnionFrom{ 0u, 0u, vr_pack10(k.rdx, k.rdy, k.rdz) }); }
+                        else vr_union_credit_esc(done, U, sink, 0u, 255u, x.esc);
                         if (U.alive_lo <= U.alive_hi)
                             vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1, t_new); }, U.holes);
                         break;
                     }
-                    while (!vr_uw_pop(U.L, path, max_trips, x, suspect)) {}
-                    if (suspect) { n_suspect++; vr_uw_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, (int)U.L.d - 1, U.L.t, U.L.c, true); }
+                    VrUnionFrom from = { 0u, 0u, vr_pack10(k.rdx, k.rdy, k.rdz) };
+                    while (!vr_uw_pop(U.L, path, max_trips, x, suspect, from)) {}
+                    if (suspect) { n_suspect++; vr_uw_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, (int)U.L.d - 1, U.L.t, U.L.c, true, from); }
+                    const bool credit = !suspect;
                     vr_uw_after_pop(U, HostFetch{ nodes });
+                    if (credit) vr_union_credit_esc(done, U, sink, U.prev_mn, U.prev_mx, x.esc);
                 }
                 if (!sink.pend) break;
                 sink.pend = false;

@@ -385,6 +385,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t x)
 #ifdef VR_DIAG /* diagnostic build only: where a wave's cycles go (never compiled into the product library) */
 __device__ unsigned long long g_diag[20];
 __device__ unsigned long long g_wave_span[3 * 8192]; /* per wave: begin, queue empty, end (s_memrealtime) */
+__device__ unsigned long long g_union_hist[3 * 128]; /* vr_k_union, per 20 us of the launch: alive lanes, sampled rounds, waves that ended */
 #define DIAG_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define DIAG_ADD(i, val) d_acc[i] += (unsigned long long)(val)
 #else
@@ -1279,13 +1280,15 @@ struct UnionNarrow {
     __device__ static __forceinline__ uint32_t depth(const ULane &, const Store &st) { return st.depth(); }
     __device__ static __forceinline__ uint32_t cell(const ULane &U) { return U.L.cell; }
     __device__ static __forceinline__ Exit move(ULane &U, const VrViewK &v) { return vr_union_move(U.L, v); }
-    __device__ static __forceinline__ bool pop(ULane &U, Store &st, const Exit &x, bool &suspect) { return vr_union_pop(U.L, st, kUnionPopTrips, x, suspect); }
+    __device__ static __forceinline__ bool pop(ULane &U, Store &st, const Exit &x, bool &suspect, VrUnionFrom &from) { return vr_union_pop(U.L, st, kUnionPopTrips, x, suspect, from); }
+    __device__ static __forceinline__ VrUnionFrom root(const VrViewK &v) { return VrUnionFrom{ 1u, 0u, v.root_hi }; }
     __device__ static __forceinline__ void leave(ULane &U, Store &st, const Exit &x, bool &suspect) { vr_union_leave(U.L, st, x, suspect); }
     template <class Done, class Sink>
     __device__ static __forceinline__ void resolve(ULane &U, const VrViewK &v, const Fetch &f, Done &done, Sink &sink, uint32_t depth_k,
-                                                   uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root)
+                                                   uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root,
+                                                   const VrUnionFrom &from)
     {
-        vr_union_resolve(U, v, f, done, sink, depth_k, cell_before, a_level, t_new, cell_new, in_root);
+        vr_union_resolve(U, v, f, done, sink, depth_k, cell_before, a_level, t_new, cell_new, in_root, from);
     }
     __device__ static __forceinline__ void after_pop(ULane &U, const Fetch &f) { vr_union_after_pop(U, f); }
 };
@@ -1307,13 +1310,15 @@ struct UnionWide {
     __device__ static __forceinline__ uint32_t depth(const ULane &U, const Store &) { return U.L.d; }
     __device__ static __forceinline__ uint32_t cell(const ULane &U) { return U.L.c; }
     __device__ static __forceinline__ Exit move(ULane &U, const VrViewK &v) { return vr_uw_move(U.L, v); }
-    __device__ static __forceinline__ bool pop(ULane &U, Store &st, const Exit &x, bool &suspect) { return vr_uw_pop(U.L, st, kUnionPopTrips, x, suspect); }
+    __device__ static __forceinline__ bool pop(ULane &U, Store &st, const Exit &x, bool &suspect, VrUnionFrom &from) { return vr_uw_pop(U.L, st, kUnionPopTrips, x, suspect, from); }
+    __device__ static __forceinline__ VrUnionFrom root(const VrViewK &v) { return VrUnionFrom{ 0u, 0u, vr_pack10(v.rdx, v.rdy, v.rdz) }; }
     __device__ static __forceinline__ void leave(ULane &U, Store &st, const Exit &x, bool &suspect) { vr_uw_leave(U.L, st, x, suspect); }
     template <class Done, class Sink>
     __device__ static __forceinline__ void resolve(ULane &U, const VrViewK &v, const Fetch &f, Done &done, Sink &sink, uint32_t depth_k,
-                                                   uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root)
+                                                   uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root,
+                                                   const VrUnionFrom &from)
     {
-        vr_uw_resolve(U, v, f, done, sink, depth_k, cell_before, a_level, t_new, cell_new, in_root);
+        vr_uw_resolve(U, v, f, done, sink, depth_k, cell_before, a_level, t_new, cell_new, in_root, from);
     }
     __device__ static __forceinline__ void after_pop(ULane &U, const Fetch &f) { vr_uw_after_pop(U, f); }
 };
@@ -1365,6 +1370,11 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     typename UOPS::Exit x = {};
     WaveChunk chunk;
     uint32_t depth_k = 0, cell_before = 0, n_states = 0;
+#ifdef VR_DIAG
+    uint32_t d_round = 0;
+    unsigned long long d_n = 0, d_c1 = 0, d_c2 = 0, d_c3 = 0, d_c4 = 0, d_l1 = 0, d_l2 = 0, d_l3 = 0, d_l4 = 0;
+    uint32_t d_res = 0, d_nres = 0;
+#endif
     bool alive = false, exhausted = false, popping = false, suspect = false;
     /* the front of a lane is finished: on with the iso values it has kept, if any, else the lane is idle (a macro, not
      * a lambda taking the two flags by reference: that kept them in scratch memory) */
@@ -1406,16 +1416,35 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             if (exhausted) break;
             continue; /* fewer idle lanes than a refill takes cannot happen with nobody alive, but stay safe */
         }
+#ifdef VR_DIAG
+        {
+            const unsigned long long d_alive = __ballot(alive);
+            if (lane == 0 && (++d_round & 15u) == 0u) { /* every 16th round of a wave is sampled */
+                uint32_t b = (uint32_t)((__builtin_amdgcn_s_memrealtime() - tick_begin) / 2000ull);
+                b = b < 127u ? b : 127u;
+                atomicAdd(&g_union_hist[3u * b], (unsigned long long)__popcll(d_alive));
+                atomicAdd(&g_union_hist[3u * b + 1u], 1ull);
+            }
+        }
+#endif
+#ifdef VR_DIAG
+        const unsigned long long d_t0 = __builtin_amdgcn_s_memtime();
+        unsigned long long d_t1 = d_t0, d_t2 = d_t0;
+        const uint32_t d_desc = wave_sum(alive && !popping ? 1u : 0u), d_fronts = (uint32_t)__popcll(__ballot(alive));
+#endif
         if (alive) {
             uint32_t go = VR_GO_MORE;
             if (!popping) go = UOPS::descend(U, fetch, stack, done, sink);
+#ifdef VR_DIAG
+            d_t1 = __builtin_amdgcn_s_memtime();
+#endif
             if (go == VR_GO_EXCLUDED) {
                 if (U.alive_lo > U.alive_hi) {
                     VR_FRONT_DONE(); /* every iso value of the front has hit */
                 } else {
                     depth_k = UOPS::depth(U, stack); cell_before = UOPS::cell(U);
                     x = UOPS::move(U, v);
-                    suspect = x.esc != 0u;
+                    suspect = false; /* set where a box that is left does not share the front's exit plane */
                     if (++n_states > kUnionMaxStates) { /* safety valve: the iso values left are reported as errors */
                         vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); }, U.holes);
                         sink.pend = false; sink.pend2 = false;
@@ -1424,7 +1453,14 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                         /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
                         const float t_new = U.L.t;
                         UOPS::leave(U, stack, x, suspect);
-                        if (suspect) UOPS::resolve(U, v, fetch, done, sink, depth_k, cell_before, -1, t_new, 0u, false);
+#ifdef VR_DIAG
+                        const unsigned long long d_r0 = __builtin_amdgcn_s_memtime();
+#endif
+                        if (suspect) UOPS::resolve(U, v, fetch, done, sink, depth_k, cell_before, -1, t_new, 0u, false, UOPS::root(v));
+#ifdef VR_DIAG
+                        if (suspect) { d_res += (uint32_t)(__builtin_amdgcn_s_memtime() - d_r0); d_nres++; }
+#endif
+                        else vr_union_credit_esc(done, U, sink, 0u, 255u, x.esc);
                         if (U.alive_lo <= U.alive_hi)
                             vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1); }, U.holes);
                         VR_FRONT_DONE();
@@ -1433,16 +1469,38 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     }
                 }
             }
+#ifdef VR_DIAG
+            d_t2 = __builtin_amdgcn_s_memtime();
+#endif
             if (popping && alive) {
-                if (UOPS::pop(U, stack, x, suspect)) {
+                VrUnionFrom from = UOPS::root(v);
+                if (UOPS::pop(U, stack, x, suspect, from)) {
                     popping = false;
+#ifdef VR_DIAG
+                    const unsigned long long d_r0 = __builtin_amdgcn_s_memtime();
+#endif
                     if (suspect)
-                        UOPS::resolve(U, v, fetch, done, sink, depth_k, cell_before, (int)UOPS::depth(U, stack) - 1, U.L.t, UOPS::cell(U), true);
+                        UOPS::resolve(U, v, fetch, done, sink, depth_k, cell_before, (int)UOPS::depth(U, stack) - 1, U.L.t, UOPS::cell(U), true, from);
+#ifdef VR_DIAG
+                    if (suspect) { d_res += (uint32_t)(__builtin_amdgcn_s_memtime() - d_r0); d_nres++; }
+#endif
                     UOPS::after_pop(U, fetch);
+                    if (!suspect) vr_union_credit_esc(done, U, sink, U.prev_mn, U.prev_mx, x.esc);
                     if (U.alive_lo > U.alive_hi) VR_FRONT_DONE();
                 }
             }
         }
+#ifdef VR_DIAG
+        {
+            /* the stamps are taken by the lanes that were alive; the wave's figure is the latest of them */
+            const unsigned long long d_t3 = __builtin_amdgcn_s_memtime();
+            const uint32_t a = wave_max((uint32_t)(d_t1 - d_t0)), b = wave_max((uint32_t)(d_t2 - d_t0)), c = (uint32_t)(d_t3 - d_t0);
+            d_n++; d_c1 += a; d_c2 += b - a; d_c3 += c - b; d_l1 += d_desc; d_l2 += d_fronts;
+            const uint32_t r = wave_max(d_res), nr = wave_sum(d_nres); /* the longest resolution of the round, and how many there were */
+            d_c4 += r; d_l3 += nr; d_l4 += nr ? 1u : 0u;
+            d_res = 0; d_nres = 0;
+        }
+#endif
         /* ---- a run that has left a lane's front goes to an idle lane of the wave, if there is one: a front of its own,
          * walked at the same time instead of after the ray's front (which is often the longest of the wave) ---- */
         for (;;) {
@@ -1466,6 +1524,14 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             }
         }
     }
+#ifdef VR_DIAG
+    if (lane == 0) {
+        const uint32_t b = (uint32_t)((__builtin_amdgcn_s_memrealtime() - tick_begin) / 2000ull);
+        atomicAdd(&g_union_hist[3u * (b < 127u ? b : 127u) + 2u], 1ull);
+        atomicAdd(&g_diag[0], d_n); atomicAdd(&g_diag[1], d_c1); atomicAdd(&g_diag[2], d_c2); atomicAdd(&g_diag[3], d_c3);
+        atomicAdd(&g_diag[4], d_l1); atomicAdd(&g_diag[5], d_l2); atomicAdd(&g_diag[6], d_c4); atomicAdd(&g_diag[7], d_l3); atomicAdd(&g_diag[8], d_l4);
+    }
+#endif
 
     {
         const uint32_t w_walks = wave_sum(n_walks);
@@ -2057,7 +2123,24 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z);
-        if (sweep) {
+        if (use_union) {
+            fprintf(stderr, "[diag union] rounds %llu; cycles per round: descend %.0f, MOVE / leave / resolve %.0f, pop %.0f; lanes descending per round %.1f, fronts %.1f\n",
+                    h[0], (double)h[1] / (double)h[0], (double)h[2] / (double)h[0], (double)h[3] / (double)h[0], (double)h[4] / (double)h[0],
+                    (double)h[5] / (double)h[0]);
+            fprintf(stderr, "[diag union] exact resolutions: %.2f per round, rounds with one %.0f%%, cycles of the longest one per round %.0f\n",
+                    (double)h[7] / (double)h[0], 100.0 * (double)h[8] / (double)h[0], (double)h[6] / (double)h[0]);
+            static unsigned long long uh[3 * 128], uz[3 * 128];
+            (void)hipMemcpyFromSymbol(uh, HIP_SYMBOL(g_union_hist), sizeof uh);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_union_hist), uz, sizeof uz);
+            unsigned long long ended = 0;
+            fprintf(stderr, "[diag union] per 20 us of the launch: sampled rounds (1 in 16), lanes with a front per round, waves ended so far\n");
+            for (int b = 0; b < 128; b++) {
+                ended += uh[3 * b + 2];
+                if (uh[3 * b + 1] || uh[3 * b + 2])
+                    fprintf(stderr, "[diag union] %4d us  rounds %6llu  fronts/round %5.1f  ended %llu\n", b * 20, uh[3 * b + 1],
+                            uh[3 * b + 1] ? (double)uh[3 * b] / (double)uh[3 * b + 1] : 0.0, ended);
+            }
+        } else if (sweep) {
             static unsigned long long span[3 * 8192];
             (void)hipMemcpyFromSymbol(span, HIP_SYMBOL(g_wave_span), sizeof span);
             const uint32_t nw = (uint32_t)h[3] < 8192u ? (uint32_t)h[3] : 8192u;

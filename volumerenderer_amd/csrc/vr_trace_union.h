@@ -250,9 +250,38 @@ VR_HD void vr_union_after_pop(VrUnionLane &U, const Fetch &fetch)
     U.prev_mn = n & 0xffu; U.prev_mx = (n >> 8) & 0xffu;
 }
 
-/* vr_lane_move (MOVE + escape help, src/raytrace.zig:199-242) that also says which plane gave t: `sh` = the field
- * shift of that axis, `ex` = the exit planes of the box that was left (max where the ray travels in +, else min). */
-struct VrUnionExit { uint32_t ex, sh, esc; bool in_root; };
+/* The escape helps of a MOVE whose popped boxes all share the front's exit plane.  Every iso value that made the MOVE --
+ * the ones not done in [mn, mx], the range of the ancestor the front came to ([0, 255] when it left the volume) -- started
+ * from the same t (same plane, same division) and ran the same escape loop: the loop of a popped box B_m goes on while
+ * the point is inside B_m, the front's while it is inside its own box B_k, a part of B_m; the front's last point is
+ * outside B_m (that is why B_m was popped), and a point outside B_m is outside B_k, so both stop at the same step. */
+template <class Done, class ULane, class Sink>
+VR_HD void vr_union_credit_esc(const Done &done, const ULane &U, Sink &sink, uint32_t mn, uint32_t mx, uint32_t esc)
+{
+    if (esc == 0u) return;
+    const uint32_t p = mn > U.alive_lo ? mn : U.alive_lo, q = mx < U.alive_hi ? mx : U.alive_hi;
+    if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.esc(r0, r1, esc); }, U.holes);
+}
+
+/* vr_lane_move (MOVE + escape help, src/raytrace.zig:199-242) that also says which planes gave t: `ex` = the exit
+ * planes of the box that was left (max where the ray travels in +, else min), `tied` = all ones in the field of every
+ * axis whose plane gave exactly the smallest t (one axis as a rule; more where the ray goes through an edge of the cell
+ * lattice, which rays from a camera at integer coordinates do all the time). */
+struct VrUnionExit { uint32_t ex, tied, esc; bool in_root; };
+
+/* Does the MOVE out of a larger box -- exit planes ex_a, each the same as the left box's or farther along the ray --
+ * start from the same t?  Its t is the smallest over the planes; those it shares with the left box give the left box's
+ * values, the others give larger ones.  So it does iff it shares the plane of an axis that gave the left box's t:
+ * a zero field of (ex_a ^ ex) among the tied ones. */
+VR_HD bool vr_union_same_exit(uint32_t ex_a, const uint32_t ex, const uint32_t tied)
+{
+    const uint32_t e = (ex_a ^ ex) | ~tied;
+    return ((e - VR_F_ONES) & ~e & (VR_F_ONES << 9)) != 0u;
+}
+
+/* A node of the front's path and its box: where the exact resolution of a MOVE starts its walk down the old path (the
+ * lowest ancestor whose box still holds the new point; the root when the front has left the volume). */
+struct VrUnionFrom { uint32_t node, lo, hi; };
 
 VR_HD VrUnionExit vr_union_move(VrLane &L, const VrViewK &v)
 {
@@ -262,7 +291,7 @@ VR_HD VrUnionExit vr_union_move(VrLane &L, const VrViewK &v)
     const float ty = vr_plane_t_r((float)((x.ex >> 10) & 0xffu), v.oy, L.dy, L.ry);
     const float tz = vr_plane_t_r((float)((x.ex >> 20) & 0xffu), v.oz, L.dz, L.rz);
     float t = fminf(fminf(tx, ty), tz);
-    x.sh = t == tx ? 0u : (t == ty ? 10u : 20u);
+    x.tied = (t == tx ? 0x3ffu : 0u) | (t == ty ? 0x3ffu << 10 : 0u) | (t == tz ? 0x3ffu << 20 : 0u);
     t += 0.0001f;
     float i = 0.0f;
     x.esc = 0u;
@@ -285,28 +314,29 @@ VR_HD VrUnionExit vr_union_move(VrLane &L, const VrViewK &v)
  * child (see vr_lane_pop), checking on the way that every box the point has left shares the front's exit plane
  * (`suspect` is set otherwise).  At most max_trips levels per call; true when the other child was entered. */
 template <class Stack>
-VR_HD bool vr_union_pop(VrLane &L, Stack &stack, uint32_t max_trips, const VrUnionExit &x, bool &suspect)
+VR_HD bool vr_union_pop(VrLane &L, Stack &stack, uint32_t max_trips, const VrUnionExit &x, bool &suspect, VrUnionFrom &from)
 {
     const uint32_t cg = L.cell | VR_F_GUARD, cp = L.cell + VR_F_ONES;
     uint32_t next = stack.peek_up(1);
-    uint32_t word = 0;
+    uint32_t word = 0, a_lo = 0, a_hi = 0;
     bool left = false, found = false;
     for (uint32_t trip = 0; trip < max_trips; trip++) {
         word = next;
         stack.up();
         next = stack.peek_up(1);
         left = (L.g & 1u) == 0u;
-        const uint32_t a_lo = left ? L.lo : word, a_hi = left ? word : L.hi;
+        a_lo = left ? L.lo : word; a_hi = left ? word : L.hi;
         const uint32_t a = cg - a_lo, b = (a_hi | VR_F_GUARD) - cp;
         found = ((a & b) & VR_F_GUARD) == VR_F_GUARD;
         if (found) break;
         /* the parent's box is left as well: the iso values parked there make their own MOVE out of it */
         const uint32_t ex_a = (a_hi & L.posmask) | (a_lo & ~L.posmask);
-        suspect = suspect || (((ex_a ^ x.ex) >> x.sh) & 0x3ffu) != 0u;
+        suspect = suspect || !vr_union_same_exit(ex_a, x.ex, x.tied);
         L.lo = a_lo; L.hi = a_hi;
         L.g >>= 1;
     }
     if (!found) return false;
+    from.node = L.g >> 1; from.lo = a_lo; from.hi = a_hi; /* the ancestor that holds the new point */
     const uint32_t cut = left ? L.hi : L.lo, keep = left ? L.lo : L.hi;
     const uint32_t carry = ((word ^ cut) + 0xffu * VR_F_ONES) & VR_F_GUARD;
     const uint32_t fm = carry - (carry >> 8);
@@ -324,12 +354,12 @@ template <class Stack>
 VR_HD void vr_union_leave(VrLane &L, Stack &stack, const VrUnionExit &x, bool &suspect)
 {
     while (stack.depth() > 0u) {
-        const uint32_t word = stack.peek_up(0);
+        const uint32_t word = stack.peek_up(1); /* the top entry: the bound the last split replaced */
         stack.up();
         const bool left = (L.g & 1u) == 0u;
         const uint32_t a_lo = left ? L.lo : word, a_hi = left ? word : L.hi;
         const uint32_t ex_a = (a_hi & L.posmask) | (a_lo & ~L.posmask);
-        suspect = suspect || (((ex_a ^ x.ex) >> x.sh) & 0x3ffu) != 0u;
+        suspect = suspect || !vr_union_same_exit(ex_a, x.ex, x.tied);
         L.lo = a_lo; L.hi = a_hi;
         L.g >>= 1;
     }
@@ -337,18 +367,20 @@ VR_HD void vr_union_leave(VrLane &L, Stack &stack, const VrUnionExit &x, bool &s
 
 /* Exact resolution of a suspect MOVE.  The front stood on the node at heap position g_k (level depth_k) with point
  * cell `cell_before`, left its box and came to the state (t_new, cell_new, in_root_new) with `esc_k` escape helps; its
- * lowest ancestor that holds the new point is at level `a_level` (all levels left: a_level = -1).  For every level m
- * in (a_level, depth_k] the iso values parked there (present at m - 1, excluded at m, not done) make their own MOVE
- * out of the box of level m: same state as the front's -> they get its escape helps, if any; another state -> they
- * leave the union walk (sink.except) and are marked done.  Walks the path again from the root, in registers. */
+ * lowest ancestor that holds the new point is `from`, at level `a_level` (all levels left: a_level = -1, from = the
+ * root).  For every level m in (a_level, depth_k] the iso values parked there (present at m - 1, excluded at m, not
+ * done) make their own MOVE out of the box of level m: same state as the front's -> they get its escape helps, if any;
+ * another state -> they leave the union walk (sink.except) and are marked done.  Walks the old path again from that
+ * ancestor down, in registers (a chain of dependent node reads: from the root it was four times as long). */
 template <class Fetch, class Done, class Sink>
 VR_HD void vr_union_resolve(VrUnionLane &U, const VrViewK &v, const Fetch &fetch, Done &done, Sink &sink, uint32_t depth_k,
-                            uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root_new)
+                            uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root_new,
+                            const VrUnionFrom &from)
 {
     VrLane T = U.L; /* the ray; box, node and point are set below */
-    uint32_t g = 1u, lo = 0u, hi = v.root_hi, prev_mn = 0u, prev_mx = 255u;
+    uint32_t g = from.node, lo = from.lo, hi = from.hi, prev_mn = 0u, prev_mx = 255u;
     bool marked = false;
-    for (uint32_t m = 0; m <= depth_k; m++) {
+    for (uint32_t m = a_level < 0 ? 0u : (uint32_t)a_level; m <= depth_k; m++) {
         const uint32_t n = fetch(g);
         const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
         if ((int)m > a_level) {

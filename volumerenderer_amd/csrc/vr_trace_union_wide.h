@@ -78,16 +78,12 @@ VR_HD uint32_t vr_uw_descend(VrUnionWideLane &U, const Fetch &fetch, Path &path,
     return VR_GO_MORE;
 }
 
-/* vr_wide_move (MOVE + escape help, src/raytrace.zig:199-246) that also says which plane gave t: `sh` = the field shift
- * of that axis, `plane` = the exit plane of the box that was left on it (its upper bound where the ray travels in +,
- * else its lower one).  in_root false: the point has left the volume (L.c, L.in3, L.k are not set then). */
-struct VrUnionWideExit { uint32_t plane, sh, esc; bool in_root; };
-
-VR_HD uint32_t vr_uw_far_plane(const VrWideLane &L, uint32_t lo, uint32_t hi, uint32_t sh)
-{
-    const float d = sh == 0u ? L.dx : (sh == 10u ? L.dy : L.dz);
-    return vr_wide_field(d >= 0.0f ? hi : lo, sh);
-}
+/* vr_wide_move (MOVE + escape help, src/raytrace.zig:199-246) that also says which planes gave t, as vr_union_move does:
+ * `ex` = the exit planes of the box that was left (its upper bound where the ray travels in +, else its lower one),
+ * `tied` = all ones in the field of every axis whose plane gave exactly the smallest t, `pm` = all ones in the field of
+ * every axis the ray travels in the + direction.  in_root false: the point has left the volume (L.c, L.in3, L.k are
+ * not set then). */
+struct VrUnionWideExit { uint32_t ex, tied, pm, esc; bool in_root; };
 
 VR_HD VrUnionWideExit vr_uw_move(VrWideLane &L, const VrViewK &v)
 {
@@ -99,8 +95,9 @@ VR_HD VrUnionWideExit vr_uw_move(VrWideLane &L, const VrViewK &v)
     const float ty = vr_plane_t_r(L.dy >= 0.0f ? hy : ly, v.oy, L.dy, L.ry);
     const float tz = vr_plane_t_r(L.dz >= 0.0f ? hz : lz, v.oz, L.dz, L.rz);
     float t = fminf(fminf(tx, ty), tz);
-    x.sh = t == tx ? 0u : (t == ty ? 10u : 20u);
-    x.plane = vr_uw_far_plane(L, lo, hi, x.sh);
+    x.pm = (L.dx >= 0.0f ? 0x3ffu : 0u) | (L.dy >= 0.0f ? 0x3ffu << 10 : 0u) | (L.dz >= 0.0f ? 0x3ffu << 20 : 0u);
+    x.ex = (hi & x.pm) | (lo & ~x.pm);
+    x.tied = (t == tx ? 0x3ffu : 0u) | (t == ty ? 0x3ffu << 10 : 0u) | (t == tz ? 0x3ffu << 20 : 0u);
     t += 0.0001f;
     float px, py, pz, i = 0.0f;
     x.esc = 0u;
@@ -129,7 +126,7 @@ VR_HD VrUnionWideExit vr_uw_move(VrWideLane &L, const VrViewK &v)
 /* vr_wide_pop for the union walk: undoes splits from the bottom until the box holds the new point, checking that
  * every box the point has left shares the front's exit plane (`suspect` otherwise), then takes the other child. */
 template <class Path>
-VR_HD bool vr_uw_pop(VrWideLane &L, Path &path, uint32_t max_trips, const VrUnionWideExit &x, bool &suspect)
+VR_HD bool vr_uw_pop(VrWideLane &L, Path &path, uint32_t max_trips, const VrUnionWideExit &x, bool &suspect, VrUnionFrom &from)
 {
     uint32_t lo = L.lo, hi = L.hi, in3 = L.in3, k = L.k, e = 0;
     const uint32_t c = L.c;
@@ -148,11 +145,12 @@ VR_HD bool vr_uw_pop(VrWideLane &L, Path &path, uint32_t max_trips, const VrUnio
         const uint32_t ok = vr_wide_field(lo, sh) <= ca && ca < vr_wide_field(hi, sh) ? 1u : 0u;
         in3 = (in3 & ~(1u << axis)) | (ok << axis);
         /* the box of level k is left as well: the iso values parked there make their own MOVE out of it */
-        if (in3 != 7u) suspect = suspect || vr_uw_far_plane(L, lo, hi, x.sh) != x.plane;
+        if (in3 != 7u) suspect = suspect || !vr_union_same_exit((hi & x.pm) | (lo & ~x.pm), x.ex, x.tied);
     }
     L.lo = lo; L.hi = hi;
     if (k < L.d) {
         L.idx = ((L.idx + 1u) >> (L.d - k)) - 1u;
+        from.node = L.idx; from.lo = lo; from.hi = hi; /* the ancestor that holds the new point */
         path.set(k, vr_wide_split(L, e & 0x3ffu, (e >> 10) & 3u, (e >> 12) & 31u));
         L.d = k + 1u;
     }
@@ -171,7 +169,7 @@ VR_HD void vr_uw_leave(VrWideLane &L, Path &path, const VrUnionWideExit &x, bool
         const uint32_t keep = ~(0x3ffu << sh), put = old << sh;
         if (e & (1u << 17)) lo = (lo & keep) | put;
         else hi = (hi & keep) | put;
-        suspect = suspect || vr_uw_far_plane(L, lo, hi, x.sh) != x.plane;
+        suspect = suspect || !vr_union_same_exit((hi & x.pm) | (lo & ~x.pm), x.ex, x.tied);
     }
 }
 
@@ -187,19 +185,20 @@ VR_HD void vr_uw_after_pop(VrUnionWideLane &U, const Fetch &fetch)
  * MOVE out of that level's box, which is compared with the front's state (t_new, cell_new, in_root_new). */
 template <class Fetch, class Done, class Sink>
 VR_HD void vr_uw_resolve(VrUnionWideLane &U, const VrViewK &v, const Fetch &fetch, Done &done, Sink &sink, uint32_t depth_k,
-                         uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root_new)
+                         uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root_new, const VrUnionFrom &from)
 {
     VrWideLane T = U.L; /* the ray; box, node and point are set below */
-    T.idx = 0u; T.d = 0u; T.lo = 0u; T.hi = vr_pack10(v.rdx, v.rdy, v.rdz); T.c = cell_before;
+    const uint32_t m0 = a_level < 0 ? 0u : (uint32_t)a_level; /* the walk starts at the ancestor `from` (see vr_union_resolve) */
+    T.idx = from.node; T.d = m0; T.lo = from.lo; T.hi = from.hi; T.c = cell_before;
     uint32_t prev_mn = 0u, prev_mx = 255u;
     bool marked = false;
-    for (uint32_t m = 0; m <= depth_k; m++) {
+    for (uint32_t m = m0; m <= depth_k; m++) {
         const uint32_t n = fetch(T.idx);
         const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
         if ((int)m > a_level) {
             bool worked_out = false, same = false;
             VrUnionWideExit own;
-            own.esc = 0u; own.in_root = false; own.plane = 0u; own.sh = 0u;
+            own.esc = 0u; own.in_root = false; own.ex = 0u; own.tied = 0u; own.pm = 0u;
             float own_t = 0.0f;
             uint32_t own_cell = 0u;
             auto each = [&](uint32_t r0, uint32_t r1) {
