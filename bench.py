@@ -50,7 +50,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-KERNEL_SOURCES = ["vr_kernels.hip", "vr_trace_core.h", "vr_trace_wide.h"]
+KERNEL_SOURCES = ["vr_kernels.hip", "vr_trace_core.h", "vr_trace_wide.h", "vr_trace_union.h", "vr_trace_union_wide.h"]
 
 
 def kernel_sources_sha():

@@ -35,7 +35,7 @@ for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
         if m:
             agg[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
 h = hashlib.sha256()
-for name in ["vr_kernels.hip", "vr_trace_core.h", "vr_trace_wide.h"]:
+for name in ["vr_kernels.hip", "vr_trace_core.h", "vr_trace_wide.h", "vr_trace_union.h", "vr_trace_union_wide.h"]:
     h.update(open(os.path.join(root, "volumerenderer_amd", "csrc", name), "rb").read())
 summary = {"workload": workload, "commit": commit, "kernel_sources_sha": h.hexdigest()[:16],
            "command": "rocprofv3 --pmc <one pass per run> -- python3 bench.py --steps 2 --warmup 1 --settle 0 --no-cpu-baseline --no-host-delivered " + " ".join(sys.argv[4:]),
@@ -48,7 +48,7 @@ if stats:
     shutil.copy(stats[0], "%s/r02_stats_%s.csv" % (out, workload))
 print(workload, "kernel_ms %.3f" % bench["roofline"]["kernel_ms"], "step %.3f" % bench["ms_per_step"])
 for k, d in summary["kernels"].items():
-    if k in ("vr_k_sweep", "vr_k_trace", "vr_k_trace_wide"):
+    if k in ("vr_k_union", "vr_k_sweep", "vr_k_trace", "vr_k_trace_wide"):
         for c in sorted(d):
             print("  %-14s %-34s %.5g" % (k, c, d[c]))
 PY
