@@ -1623,6 +1623,9 @@ __global__ __launch_bounds__(64) void vr_k_union_fix(VrViewK v, const uint32_t *
             }
         }
     }
+    /* the sweep's report ends where its last piece of work ends: the cut of the iso range is judged by that */
+    if (blockIdx.x < count && threadIdx.x == 0)
+        atomicMax((unsigned long long *)(n_active_ptr + 16) + 4, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 /* vr_k_union_fix for wide trees */
@@ -1674,6 +1677,9 @@ __global__ __launch_bounds__(64) void vr_k_union_fix_wide(VrViewK v, const uint3
             }
         }
     }
+    /* the sweep's report ends where its last piece of work ends: the cut of the iso range is judged by that */
+    if (blockIdx.x < count && threadIdx.x == 0)
+        atomicMax((unsigned long long *)(n_active_ptr + 16) + 4, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 /* ------------------------------------------------------------------ wide volumes ---- */
