@@ -61,6 +61,42 @@ def test_union_kernel_equals_per_iso_kernel_at_full_size(oracle, skull_vox, skul
     assert si.walks == si.items and si.walks >= 250000  # one traversal per entering ray and block of iso values
 
 
+def test_union_kernel_repeated_calls_start_their_tiles_longest_first_with_the_same_results(oracle, skull_vox, skull_renderer,
+                                                                                          c60_vox, c60_renderer):
+    """A call that repeats the last call of its context exactly starts its tiles in the order of the lengths the last
+    launch left (longest first); a different call in between ends that.  Frames and all counters never depend on it:
+    Skull 1024^2 (all 256 iso values, then rows 100..900, then the whole again) and C60 at a ragged size, four times each,
+    against the first call and the kernel with one traversal per iso value."""
+    import torch
+    L = capi.lib()
+
+    def run(rnd, v, W, r0, r1, b, n, variant):
+        rnd.set_kernel(variant)
+        d_rgb = torch.empty((n, r1 - r0, W, 3), dtype=torch.uint8, device="cuda")
+        d_stats = torch.zeros((n, 7), dtype=torch.int64, device="cuda")
+        capi.check(L.vr_render_device(rnd.handle, C.byref(v), b, n, r0, r1, d_rgb.data_ptr(), d_stats.data_ptr(), None, None),
+                   "vr_render_device")
+        capi.check(L.vr_sync(rnd.handle), "vr_sync")
+        rnd.set_kernel(capi.KERNEL_DEFAULT)
+        return d_rgb, d_stats.cpu().numpy()
+
+    for vox, rnd, W, H, b, n in [(skull_vox, skull_renderer, 1024, 1024, 0, 256), (c60_vox, c60_renderer, 333, 217, 3, 250)]:
+        pos, forw, up = oracle.main_camera(vox.shape)
+        v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+        ref = run(rnd, v, W, 0, H, b, n, capi.KERNEL_PIPELINE)
+        for i in range(4):
+            got = run(rnd, v, W, 0, H, b, n, capi.KERNEL_UNION)
+            assert (got[1] == ref[1]).all(), (i, np.argwhere(got[1] != ref[1])[:8])
+            assert bool(torch.equal(got[0], ref[0])), i
+        r0, r1 = H // 10, H - H // 8
+        for i in range(2):
+            part = run(rnd, v, W, r0, r1, b, n, capi.KERNEL_UNION)
+            assert bool(torch.equal(part[0], ref[0][:, r0:r1])), i
+        for i in range(3):
+            got = run(rnd, v, W, 0, H, b, n, capi.KERNEL_UNION)
+            assert (got[1] == ref[1]).all() and bool(torch.equal(got[0], ref[0])), i
+
+
 def test_union_kernel_on_the_256_cubed_volume_at_full_size(oracle, standin_tree, standin_renderer):
     """The 256^3 stand-in (depth-24 tree) at 1024^2, iso 0..255: the union kernel equals the kernel with traversals
     shared between iso values, frames and counters; so do two row ranges and a band shard rendered on their own."""

@@ -74,6 +74,16 @@ struct vr_ctx {
         uint64_t cur_span = ~0ull;         /* its shortest launch so far */
         uint32_t ipl_of_seq[16] = { 0 };
     } tune;
+    /* The last call that ran in d_work, if it was one of the kernel with one traversal per ray: that kernel leaves, per tile
+     * of 64 rays, the length of the tile's longest item behind the workspace, and the next call that is the same in every
+     * respect (tree, view, rows, iso range) starts its tiles longest first.  Any other call in between ends that. */
+    struct LastUnion {
+        bool have = false;
+        uint64_t tree_id = 0;
+        VrViewK view;
+        uint32_t iso_begin = 0, iso_count = 0, row_begin = 0, row_end = 0;
+        void *work = nullptr;
+    } last_union;
     uint64_t tree_id = 0;                 /* changes with every upload / build */
     unsigned long long *h_info = nullptr; /* page-locked: walks, items, 3 ticks, sequence number */
     /* options */
@@ -506,6 +516,14 @@ static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, 
     *seq_out = t.seq;
 }
 
+/* the same view, field by field (the struct has padding; the fifteen floats at its start are compared as bit patterns) */
+static bool same_view(const VrViewK &a, const VrViewK &b)
+{
+    return std::memcmp(&a.ox, &b.ox, 15u * sizeof(float)) == 0 && a.width == b.width && a.height == b.height && a.root_hi == b.root_hi &&
+           a.rdx == b.rdx && a.rdy == b.rdy && a.rdz == b.rdz && a.n_slots == b.n_slots && a.band_rows == b.band_rows &&
+           a.band_pitch == b.band_pitch;
+}
+
 /* Shared body of the two device-resident entry points.  `fixed_scratch` = null: the context's own workspace,
  * grown on demand (the only allocation on that path).  Otherwise the pipeline runs in `fixed_scratch`
  * (fixed_bytes long) and nothing is allocated or created. */
@@ -542,7 +560,8 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
     } else {
         if (!per_pixel) {
             /* growing the scratch is the only allocation on this path; it happens when a larger view comes */
-            const size_t need = vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count);
+            const size_t need = ((vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count) + 255) & ~(size_t)255) +
+                                vr_pipeline_lpt_bytes(view->width, row_end - row_begin);
             if (need > c->work_cap) VR_HIP(hipStreamSynchronize(s));
             rc = ensure(&c->d_work, &c->work_cap, need);
             if (rc != VR_OK) return rc;
@@ -571,13 +590,28 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
     if (forced_ipl) ipl = forced_ipl;
     else if ((sweep_kernel || union_kernel) && !fixed_scratch)
         sweep_tune_next(c, view, iso_begin, iso_count, row_begin, row_end - row_begin, band_rows, union_kernel, &ipl, &seq);
+    /* tiles longest first when the last call in this workspace was this very call (see vr_ctx::LastUnion) */
+    static const bool lpt_off = std::getenv("VR_UNION_LPT") && std::atoi(std::getenv("VR_UNION_LPT")) == 0; /* for A/B runs */
+    int lpt_mode = 0;
+    if (!fixed_scratch && !per_pixel) {
+        vr_ctx::LastUnion &u = c->last_union;
+        if (union_kernel && !lpt_off) {
+            const bool same = u.have && u.tree_id == c->tree_id && u.work == work && same_view(u.view, k) &&
+                              u.iso_begin == iso_begin && u.iso_count == iso_count && u.row_begin == row_begin && u.row_end == row_end;
+            lpt_mode = same ? 2 : 1;
+            u.tree_id = c->tree_id; u.view = k;
+            u.iso_begin = iso_begin; u.iso_count = iso_count; u.row_begin = row_begin; u.row_end = row_end; u.work = work;
+        }
+        u.have = false; /* until the launch is known to be enqueued */
+    }
     if (c->wide)
         VR_HIP(vr_launch_render_wide(variant, s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
-                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq, c->ranges_nested));
+                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq, c->ranges_nested, lpt_mode));
     else
         VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
                                 row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq,
-                                c->ranges_nested));
+                                c->ranges_nested, lpt_mode));
+    if (lpt_mode) c->last_union.have = true;
     if (timing) c->ev_used += 2;
     if ((sweep_kernel || union_kernel) && !fixed_scratch) {
         c->info_off = vr_pipeline_info_offset(view->width, row_end - row_begin);

@@ -49,6 +49,12 @@ extern "C" int vr_host_check_kdt_wide_nested(const uint32_t *nodes, uint64_t n_s
 /* Device scratch the pipeline variant needs for one call (ray list, tile offsets, queue heads). */
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count);
 
+/* Behind the pipeline workspace of a call (rounded up to 256 bytes): what the kernel with one traversal per ray keeps from
+ * launch to launch of the same call -- per tile of 64 rays the length of its longest item, and the order of the tiles made
+ * from it.  lpt_mode of the launchers: 0 = the arrays are not there (nothing kept, list order), 1 = keep the lengths of
+ * this launch, 2 = the lengths of the previous launch of this very call are in place: longest tiles first, keep again. */
+size_t vr_pipeline_lpt_bytes(uint32_t width, uint32_t n_rows);
+
 /* Byte offset, inside the pipeline workspace of a call, of the sweep kernel's 40-byte report (vr_sweep_info). */
 size_t vr_pipeline_info_offset(uint32_t width, uint32_t n_rows);
 
@@ -59,7 +65,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                             const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
                             const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end,
-                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested);
+                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested, int lpt_mode);
 
 /* Once per device, with that device current (vr_ctx_create calls it; safe from several threads): raises the
  * dynamic-LDS ceiling of the persistent kernels, which is a property of the function on the device, and looks
@@ -95,7 +101,7 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
                                  uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
                                  hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq,
-                                 bool ranges_nested);
+                                 bool ranges_nested, int lpt_mode);
 
 
 /* One ray with the literal loop, every iteration recorded (vr_refine.hip): d_steps holds cap records, d_report one. */

@@ -1146,6 +1146,68 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
 
 /* ------------------------------------------------------------------ union walk ---- */
 
+/* Order of the tiles (groups of 64 consecutive rays of the list) for the next union launch of the same view: longest
+ * first.  tile_cost holds, per tile, the largest number of rounds one lane spent on one of its items in the previous
+ * launch; the tiles are put into 16 classes by that length (relative to the longest) and the classes are laid out one
+ * after the other, longest first, each in list order (tiles that lie next to each other in the image stay together).
+ * A launch ends with its longest fronts; starting them first shortens the time the grid spends draining.  One block;
+ * clears tile_cost for the launch that follows. */
+constexpr uint32_t kLptClasses = 16;
+__global__ __launch_bounds__(1024) void vr_k_tile_order(const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ tile_cost,
+                                                        uint32_t *__restrict__ tile_order)
+{
+    __shared__ uint32_t s_max[16];
+    __shared__ uint32_t s_cnt[16][kLptClasses]; /* per wave and class: tiles, then where the wave's tiles of the class begin */
+    const uint32_t n_tiles = (*n_active_ptr + 63u) >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t per_wave = ((n_tiles + 15u) / 16u + 63u) & ~63u;
+    const uint32_t w0 = wave * per_wave < n_tiles ? wave * per_wave : n_tiles;
+    const uint32_t w1 = w0 + per_wave < n_tiles ? w0 + per_wave : n_tiles;
+    uint32_t mx = 0;
+    for (uint32_t g = w0 + lane; g < w1; g += 64u) mx = tile_cost[g] > mx ? tile_cost[g] : mx;
+    mx = wave_max(mx);
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    mx = 0;
+    for (uint32_t w = 0; w < 16u; w++) mx = s_max[w] > mx ? s_max[w] : mx;
+    const uint64_t scale = (uint64_t)mx + 1u;
+    uint32_t cnt[kLptClasses];
+#pragma unroll
+    for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] = 0;
+    for (uint32_t g0 = w0; g0 < w1; g0 += 64u) {
+        const uint32_t g = g0 + lane;
+        const uint32_t cls = g < w1 ? (kLptClasses - 1u) - (uint32_t)(((uint64_t)tile_cost[g] * kLptClasses) / scale) : kLptClasses;
+#pragma unroll
+        for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] += (uint32_t)__popcll(__ballot(cls == c));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (uint32_t c = 0; c < kLptClasses; c++) s_cnt[wave][c] = cnt[c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { /* 256 counts to starting positions: class-major, waves in order inside a class */
+        uint32_t run = 0;
+        for (uint32_t c = 0; c < kLptClasses; c++)
+            for (uint32_t w = 0; w < 16u; w++) { const uint32_t n = s_cnt[w][c]; s_cnt[w][c] = run; run += n; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] = s_cnt[wave][c];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t g0 = w0; g0 < w1; g0 += 64u) {
+        const uint32_t g = g0 + lane;
+        const uint32_t cls = g < w1 ? (kLptClasses - 1u) - (uint32_t)(((uint64_t)tile_cost[g] * kLptClasses) / scale) : kLptClasses;
+#pragma unroll
+        for (uint32_t c = 0; c < kLptClasses; c++) {
+            const unsigned long long b = __ballot(cls == c);
+            if (cls == c) tile_order[cnt[c] + (uint32_t)__popcll(b & below)] = g;
+            cnt[c] += (uint32_t)__popcll(b);
+        }
+        if (g < w1) tile_cost[g] = 0u;
+    }
+}
+
+
 /* vr_k_union: the sweep as ONE traversal per ray (lane code and the idea: vr_trace_union.h).  Work items are rays;
  * a lane keeps the 256 done bits of its ray in LDS next to its path stack.  Per-iso counters go through the same
  * difference arrays in LDS as in vr_k_sweep.  Iso values whose own MOVE does not land on the front's state (a few in
@@ -1328,7 +1390,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top, uint32_t stack_rows, const float4 *__restrict__ ray_dt,
     const uint32_t *__restrict__ ray_pix, const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ head, uint32_t iso_begin,
     uint32_t iso_count, uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
-    VrUnionRecord *__restrict__ except_list, uint32_t except_cap, uint32_t items_per_lane, uint32_t launch_seq)
+    VrUnionRecord *__restrict__ except_list, uint32_t except_cap, uint32_t items_per_lane, uint32_t launch_seq,
+    const uint32_t *__restrict__ tile_order, uint32_t *__restrict__ tile_cost)
 {
     /* dynamic LDS: [path stacks][check sums and counters as in vr_k_sweep][done bits: 8 x kTraceThreads words][top node words] */
     extern __shared__ uint32_t s_dyn[];
@@ -1370,6 +1433,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     typename UOPS::Exit x = {};
     WaveChunk chunk;
     uint32_t depth_k = 0, cell_before = 0, n_states = 0;
+    uint32_t n_rounds = 0; /* rounds this lane has spent on its item: the item's length, kept per tile for the next launch's order */
 #ifdef VR_DIAG
     uint32_t d_round = 0;
     unsigned long long d_n = 0, d_c1 = 0, d_c2 = 0, d_c3 = 0, d_c4 = 0, d_l1 = 0, d_l2 = 0, d_l3 = 0, d_l4 = 0;
@@ -1386,6 +1450,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             popping = false;                                                                                \
         } else {                                                                                            \
             alive = false;                                                                                  \
+            if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], n_rounds);                                  \
         }                                                                                                   \
     } while (0)
 
@@ -1397,7 +1462,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             uint32_t mine;
             const bool got = chunk.take(n_idle, (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), head, n_items, n_idle, lane, mine);
             if (!alive && got) {
-                const uint32_t grp = mine / (64u * n_blocks), in = mine - grp * 64u * n_blocks;
+                const uint32_t at = mine / (64u * n_blocks), in = mine - at * 64u * n_blocks;
+                const uint32_t grp = tile_order ? tile_order[at] : at; /* longest tiles of the previous launch first */
                 const uint32_t blk = in >> 6, ray = grp * 64u + (in & 63u);
                 if (ray < n_active) { /* the last group of 64 may be short */
                     const float4 r = ray_dt[ray];
@@ -1405,7 +1471,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     sink.ray = ray;
                     const uint32_t b0 = blk * block_isos, b1 = b0 + block_isos < iso_count ? b0 + block_isos : iso_count;
                     UOPS::begin(U, stack, done, v, r, iso_begin + b0, b1 - b0);
-                    alive = true; popping = false; n_states = 0;
+                    alive = true; popping = false; n_states = 0; n_rounds = 0;
                     n_walks++;
                 }
             }
@@ -1433,6 +1499,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
         const uint32_t d_desc = wave_sum(alive && !popping ? 1u : 0u), d_fronts = (uint32_t)__popcll(__ballot(alive));
 #endif
         if (alive) {
+            n_rounds++;
             uint32_t go = VR_GO_MORE;
             if (!popping) go = UOPS::descend(U, fetch, stack, done, sink);
 #ifdef VR_DIAG
@@ -1449,6 +1516,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                         vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); }, U.holes);
                         sink.pend = false; sink.pend2 = false;
                         alive = false;
+                        if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], n_rounds);
                     } else if (!x.in_root) {
                         /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
                         const float t_new = U.L.t;
@@ -1520,7 +1588,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             if (lane == taker) {
                 sink.pix = g_pix; sink.ray = g_ray;
                 UOPS::restart(U, stack, done, v, g_t, g_cell, g_runs);
-                alive = true; popping = false; n_states = 0;
+                alive = true; popping = false; n_states = 0; n_rounds = 0;
             }
         }
     }
@@ -2003,6 +2071,38 @@ size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso
     return bytes;
 }
 
+size_t vr_pipeline_lpt_bytes(uint32_t width, uint32_t n_rows)
+{
+    const size_t n_tiles = ((size_t)width * n_rows + 63u) / 64u + 1u;
+    return 2u * ((n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255); /* cost per tile, order of the tiles */
+}
+
+/* the tile costs and the tile order of the union kernel lie behind the pipeline workspace of the call */
+static void lpt_arrays(void *workspace, uint32_t width, uint32_t n_rows, uint32_t iso_count, uint32_t **cost, uint32_t **order)
+{
+    char *w = (char *)workspace + ((vr_pipeline_workspace_bytes(width, n_rows, iso_count) + 255) & ~(size_t)255);
+    *cost = (uint32_t *)w;
+    *order = (uint32_t *)(w + vr_pipeline_lpt_bytes(width, n_rows) / 2u);
+}
+
+/* Before a union launch: with the costs of the previous launch of the same call in place (lpt_mode 2) they become
+ * the order of the tiles, else (1) the costs start at zero and the tiles keep the list's order; 0 = neither kept nor used. */
+static hipError_t lpt_prepare(hipStream_t stream, int lpt_mode, void *workspace, const VrViewK &view, uint32_t n_rows, uint32_t iso_count,
+                              const uint32_t *n_active, uint32_t **order, uint32_t **cost)
+{
+    *order = nullptr; *cost = nullptr;
+    if (lpt_mode == 0) return hipSuccess;
+    uint32_t *c, *o;
+    lpt_arrays(workspace, view.width, n_rows, iso_count, &c, &o);
+    *cost = c;
+    if (lpt_mode == 2) {
+        hipLaunchKernelGGL(vr_k_tile_order, dim3(1), dim3(1024), 0, stream, n_active, c, o);
+        *order = o;
+        return hipGetLastError();
+    }
+    return hipMemsetAsync(c, 0, vr_pipeline_lpt_bytes(view.width, n_rows) / 2u, stream);
+}
+
 /* levels of the tree a persistent block keeps in LDS: what is left of the CU's 160 KiB beside the path stacks (and
  * the sweep kernel's counters), at most 14 */
 static uint32_t lds_top_levels(uint32_t max_depth, uint64_t n_slots, size_t stat_bytes)
@@ -2021,7 +2121,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                             const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
                             const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end,
-                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested)
+                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested, int lpt_mode)
 {
     const uint32_t n_rows = row_end - row_begin;
     const uint32_t stack_levels = max_depth > 0 ? max_depth : 1u;
@@ -2101,10 +2201,13 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                            (void *)&d_rgb, (void *)&d_stats, (void *)&slots, (void *)&taps };
     VrUnionRecord *except_list = (VrUnionRecord *)((char *)heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
     uint32_t except_cap = VR_UNION_EXCEPT_CAP;
+    uint32_t *tile_order = nullptr, *tile_cost = nullptr;
+    if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, n_active, &tile_order, &tile_cost)) != hipSuccess)
+        return e;
     void *args_union[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                            (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
-                           (void *)&launch_seq };
+                           (void *)&launch_seq, (void *)&tile_order, (void *)&tile_cost };
     void **args = use_union ? args_union : (sweep ? args_sweep : args_trace);
     const void *fn = use_union ? (const void *)vr_k_union<UnionNarrow>
                    : sweep ? (any_tap ? (const void *)vr_k_sweep<true, SweepNarrow> : (const void *)vr_k_sweep<false, SweepNarrow>)
@@ -2202,7 +2305,7 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
                                  uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
                                  hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq,
-                                 bool ranges_nested)
+                                 bool ranges_nested, int lpt_mode)
 {
     const uint32_t n_rows = row_end - row_begin;
     hipError_t e = hipSuccess;
@@ -2232,10 +2335,12 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
         VrUnionRecord *except_list = (VrUnionRecord *)((char *)pp.heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
         uint32_t except_cap = VR_UNION_EXCEPT_CAP;
+        uint32_t *tile_order = nullptr, *tile_cost = nullptr;
+        if ((e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, pp.n_active, &tile_order, &tile_cost)) != hipSuccess) return e;
         void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&stack_rows, (void *)&pp.ray_dt, (void *)&pp.ray_pix,
                          (void *)&pp.n_active, (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                          (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
-                         (void *)&launch_seq };
+                         (void *)&launch_seq, (void *)&tile_order, (void *)&tile_cost };
         if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
         if ((e = hipLaunchKernel((const void *)vr_k_union<UnionWide>, dim3(blocks), dim3(kTraceThreads), args, lds, stream)) != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
