@@ -140,6 +140,13 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
     return x;
 }
 
+__device__ __forceinline__ uint32_t wave_max(uint32_t x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { uint32_t y = __shfl_xor(x, off, 64); x = y > x ? y : x; }
+    return x;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long x)
 {
 #pragma unroll
@@ -294,12 +301,122 @@ __global__ __launch_bounds__(kPreThreads) void vr_k_count(VrViewK v, uint32_t ro
     if (threadIdx.x == 0) block_count[blockIdx.x] = total;
 }
 
+/* Order of the tiles (groups of 64 consecutive rays of the list) for a union launch that repeats the previous call:
+ * longest first.  tile_cost holds, per tile, the largest number of rounds one lane spent on one of the tile's items in
+ * the previous launch; the tiles are put into 16 classes by that length (relative to the longest) and the classes are
+ * laid out one after the other, longest first, each in list order (tiles that lie next to each other in the image stay
+ * together).  A launch ends with its longest fronts; starting them first shortens the time the grid spends draining.
+ * Tiles behind the end of the list have length 0 and so come last, behind every tile of the list: the first
+ * ceil(rays / 64) entries of the order are a permutation of the list's tiles.  Work of one block of 1024 threads (the
+ * second block of vr_k_scan); leaves tile_cost at zero for the launch that follows. */
+constexpr uint32_t kLptClasses = 16;
+constexpr uint32_t kLptHeaderWords = 64; /* in front of the lengths; word 0: tiles in the list of the launch that left them */
+__device__ __forceinline__ uint32_t lpt_class(uint32_t cost, float per_length)
+{
+    const uint32_t q = (uint32_t)((float)cost * per_length);
+    return (kLptClasses - 1u) - (q < kLptClasses - 1u ? q : kLptClasses - 1u);
+}
+constexpr uint32_t kLptPerLane = 16; /* lengths a lane reads at a time: the reads of a pass are in flight together */
+__device__ void tile_order_block(uint32_t n_tiles, uint32_t *__restrict__ tile_cost, uint32_t *__restrict__ tile_order)
+{
+    __shared__ uint32_t s_max[16];
+    __shared__ uint32_t s_cnt[kLptClasses * 16u]; /* [class][wave]: tiles, then where the wave's tiles of the class begin */
+    __shared__ uint32_t s_at[kLptClasses * 16u];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t per_wave = ((n_tiles + 15u) / 16u + 63u) & ~63u;
+    const uint32_t w0 = wave * per_wave < n_tiles ? wave * per_wave : n_tiles;
+    const uint32_t w1 = w0 + per_wave < n_tiles ? w0 + per_wave : n_tiles;
+    uint32_t len[kLptPerLane];
+    uint32_t mx = 0;
+    for (uint32_t g0 = w0; g0 < w1; g0 += 64u * kLptPerLane) {
+#pragma unroll
+        for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[g] : 0u; }
+#pragma unroll
+        for (uint32_t j = 0; j < kLptPerLane; j++) mx = len[j] > mx ? len[j] : mx;
+    }
+    mx = wave_max(mx);
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    mx = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16u; w++) mx = s_max[w] > mx ? s_max[w] : mx;
+    const float per_length = (float)kLptClasses / ((float)mx + 1.0f);
+    uint32_t cnt[kLptClasses];
+#pragma unroll
+    for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] = 0;
+    for (uint32_t g0 = w0; g0 < w1; g0 += 64u * kLptPerLane) {
+        if (w1 - w0 > 64u * kLptPerLane) { /* else the lengths of the wave's only chunk are still in registers */
+#pragma unroll
+            for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[g] : 0u; }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kLptPerLane; j++) {
+            if (g0 + j * 64u >= w1) break;
+            const uint32_t cls = g0 + j * 64u + lane < w1 ? lpt_class(len[j], per_length) : kLptClasses;
+#pragma unroll
+            for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] += (uint32_t)__popcll(__ballot(cls == c));
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (uint32_t c = 0; c < kLptClasses; c++) s_cnt[c * 16u + wave] = cnt[c];
+    }
+    __syncthreads();
+    /* 256 counts to starting positions: class-major, waves in order inside a class (scan in waves 0-3, then their totals) */
+    uint32_t mine = 0, incl = 0;
+    if (threadIdx.x < kLptClasses * 16u) {
+        mine = s_cnt[threadIdx.x];
+        incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(incl, off, 64);
+            incl += lane >= (uint32_t)off ? y : 0u;
+        }
+        if (lane == 63u) s_max[wave] = incl; /* every thread has read the lengths' maxima by now */
+    }
+    __syncthreads();
+    if (threadIdx.x < kLptClasses * 16u) {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; w++) before += s_max[w];
+        s_at[threadIdx.x] = before + incl - mine;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] = s_at[c * 16u + wave];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t g0 = w0; g0 < w1; g0 += 64u * kLptPerLane) {
+        if (w1 - w0 > 64u * kLptPerLane) {
+#pragma unroll
+            for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[g] : 0u; }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kLptPerLane; j++) {
+            if (g0 + j * 64u >= w1) break;
+            const uint32_t g = g0 + j * 64u + lane;
+            const uint32_t cls = g < w1 ? lpt_class(len[j], per_length) : kLptClasses;
+#pragma unroll
+            for (uint32_t c = 0; c < kLptClasses; c++) {
+                const unsigned long long b = __ballot(cls == c);
+                if (cls == c) tile_order[cnt[c] + (uint32_t)__popcll(b & below)] = g;
+                cnt[c] += (uint32_t)__popcll(b);
+            }
+            if (g < w1) tile_cost[g] = 0u;
+        }
+    }
+}
+
 /* 1b: exclusive scan of the per-block counts in place, by one block; writes the total.  Every wave takes a
  * contiguous share and goes through it 64 values at a time (coalesced), twice: totals first, then the scan. */
 __global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, uint32_t n, uint32_t *__restrict__ n_active_out,
                                                   uint32_t *__restrict__ heads, uint32_t iso_count,
-                                                  vr_render_stats *__restrict__ stats, uint64_t frame_pixels)
+                                                  vr_render_stats *__restrict__ stats, uint64_t frame_pixels, uint32_t n_tiles,
+                                                  uint32_t *__restrict__ tile_cost, uint32_t *__restrict__ tile_order)
 {
+    if (blockIdx.x == 1u) { /* launched only when the union kernel's tile order is wanted: it rides along on a block of its own */
+        const uint32_t listed = *(tile_cost - kLptHeaderWords); /* the same list as this call's: same call */
+        tile_order_block(listed < n_tiles ? listed : n_tiles, tile_cost, tile_order);
+        return;
+    }
     __shared__ uint32_t s_wave[16];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t per = ((n + 15u) / 16u + 63u) & ~63u; /* values per wave, a multiple of 64 */
@@ -376,12 +493,6 @@ __global__ void vr_k_tap_defaults(VrTapsK taps, uint64_t n, uint32_t oob_word)
 
 /* --------------------------------------------------------- pipeline: persistent trace ---- */
 
-__device__ __forceinline__ uint32_t wave_max(uint32_t x)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { uint32_t y = __shfl_xor(x, off, 64); x = y > x ? y : x; }
-    return x;
-}
 #ifdef VR_DIAG /* diagnostic build only: where a wave's cycles go (never compiled into the product library) */
 __device__ unsigned long long g_diag[20];
 __device__ unsigned long long g_wave_span[3 * 8192]; /* per wave: begin, queue empty, end (s_memrealtime) */
@@ -1146,68 +1257,6 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
 
 /* ------------------------------------------------------------------ union walk ---- */
 
-/* Order of the tiles (groups of 64 consecutive rays of the list) for the next union launch of the same view: longest
- * first.  tile_cost holds, per tile, the largest number of rounds one lane spent on one of its items in the previous
- * launch; the tiles are put into 16 classes by that length (relative to the longest) and the classes are laid out one
- * after the other, longest first, each in list order (tiles that lie next to each other in the image stay together).
- * A launch ends with its longest fronts; starting them first shortens the time the grid spends draining.  One block;
- * clears tile_cost for the launch that follows. */
-constexpr uint32_t kLptClasses = 16;
-__global__ __launch_bounds__(1024) void vr_k_tile_order(const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ tile_cost,
-                                                        uint32_t *__restrict__ tile_order)
-{
-    __shared__ uint32_t s_max[16];
-    __shared__ uint32_t s_cnt[16][kLptClasses]; /* per wave and class: tiles, then where the wave's tiles of the class begin */
-    const uint32_t n_tiles = (*n_active_ptr + 63u) >> 6;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t per_wave = ((n_tiles + 15u) / 16u + 63u) & ~63u;
-    const uint32_t w0 = wave * per_wave < n_tiles ? wave * per_wave : n_tiles;
-    const uint32_t w1 = w0 + per_wave < n_tiles ? w0 + per_wave : n_tiles;
-    uint32_t mx = 0;
-    for (uint32_t g = w0 + lane; g < w1; g += 64u) mx = tile_cost[g] > mx ? tile_cost[g] : mx;
-    mx = wave_max(mx);
-    if (lane == 0) s_max[wave] = mx;
-    __syncthreads();
-    mx = 0;
-    for (uint32_t w = 0; w < 16u; w++) mx = s_max[w] > mx ? s_max[w] : mx;
-    const uint64_t scale = (uint64_t)mx + 1u;
-    uint32_t cnt[kLptClasses];
-#pragma unroll
-    for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] = 0;
-    for (uint32_t g0 = w0; g0 < w1; g0 += 64u) {
-        const uint32_t g = g0 + lane;
-        const uint32_t cls = g < w1 ? (kLptClasses - 1u) - (uint32_t)(((uint64_t)tile_cost[g] * kLptClasses) / scale) : kLptClasses;
-#pragma unroll
-        for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] += (uint32_t)__popcll(__ballot(cls == c));
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (uint32_t c = 0; c < kLptClasses; c++) s_cnt[wave][c] = cnt[c];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { /* 256 counts to starting positions: class-major, waves in order inside a class */
-        uint32_t run = 0;
-        for (uint32_t c = 0; c < kLptClasses; c++)
-            for (uint32_t w = 0; w < 16u; w++) { const uint32_t n = s_cnt[w][c]; s_cnt[w][c] = run; run += n; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] = s_cnt[wave][c];
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t g0 = w0; g0 < w1; g0 += 64u) {
-        const uint32_t g = g0 + lane;
-        const uint32_t cls = g < w1 ? (kLptClasses - 1u) - (uint32_t)(((uint64_t)tile_cost[g] * kLptClasses) / scale) : kLptClasses;
-#pragma unroll
-        for (uint32_t c = 0; c < kLptClasses; c++) {
-            const unsigned long long b = __ballot(cls == c);
-            if (cls == c) tile_order[cnt[c] + (uint32_t)__popcll(b & below)] = g;
-            cnt[c] += (uint32_t)__popcll(b);
-        }
-        if (g < w1) tile_cost[g] = 0u;
-    }
-}
-
-
 /* vr_k_union: the sweep as ONE traversal per ray (lane code and the idea: vr_trace_union.h).  Work items are rays;
  * a lane keeps the 256 done bits of its ray in LDS next to its path stack.  Per-iso counters go through the same
  * difference arrays in LDS as in vr_k_sweep.  Iso values whose own MOVE does not land on the front's state (a few in
@@ -1250,16 +1299,17 @@ struct UnionSink {
     VrUnionRecord *except_list;
     uint32_t except_cap;
     /* iso values that left the front, kept by the lane until an idle lane of the wave takes them or the ray's current
-     * front is finished and the lane walks them itself, as a front of their own; two such states of up to four runs each
+     * front is finished and the lane walks them itself, as a front of their own; three such states of up to four runs each
      * fit, more go to the list */
-    bool pend, pend2;
-    float pend_t, pend2_t;
-    uint32_t pend_cell, pend2_cell;
-    VrUnionRuns pend_runs, pend2_runs;
+    bool pend, pend2, pend3;
+    float pend_t, pend2_t, pend3_t;
+    uint32_t pend_cell, pend2_cell, pend3_cell;
+    VrUnionRuns pend_runs, pend2_runs, pend3_runs;
     __device__ __forceinline__ void pend_shift()
     {
         pend = pend2; pend_t = pend2_t; pend_cell = pend2_cell; pend_runs = pend2_runs;
-        pend2 = false;
+        pend2 = pend3; pend2_t = pend3_t; pend2_cell = pend3_cell; pend2_runs = pend3_runs;
+        pend3 = false;
     }
     __device__ __forceinline__ void add(uint32_t counter, uint32_t r0, uint32_t r1, uint32_t amount)
     {
@@ -1312,6 +1362,14 @@ struct UnionSink {
         if (cell == pend2_cell && tb == __builtin_bit_cast(uint32_t, pend2_t) && pend2_runs.room()) {
             if (n_esc) esc(r0, r1, n_esc);
             pend2_runs.add(r0, r1);
+            return;
+        }
+        if (!pend3) {
+            pend3 = true; pend3_t = t; pend3_cell = cell; pend3_runs.clear();
+        }
+        if (cell == pend3_cell && tb == __builtin_bit_cast(uint32_t, pend3_t) && pend3_runs.room()) {
+            if (n_esc) esc(r0, r1, n_esc);
+            pend3_runs.add(r0, r1);
             return;
         }
         const uint32_t at = atomicAdd(except_count, 1u);
@@ -1429,6 +1487,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     sink.except_count = (uint32_t *)n_active_ptr + 32; sink.except_list = except_list; sink.except_cap = except_cap;
     sink.pend = false; sink.pend_t = 0.0f; sink.pend_cell = 0; sink.pend_runs.clear();
     sink.pend2 = false; sink.pend2_t = 0.0f; sink.pend2_cell = 0; sink.pend2_runs.clear();
+    sink.pend3 = false; sink.pend3_t = 0.0f; sink.pend3_cell = 0; sink.pend3_runs.clear();
     typename UOPS::ULane U;
     typename UOPS::Exit x = {};
     WaveChunk chunk;
@@ -1458,6 +1517,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
         /* ---- refill idle lanes from the ray queue ---- */
         const unsigned long long idle = __ballot(!alive);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
+        bool start = false;            /* this lane begins a front: on ray s_ray, for s_n iso values from s_iso on */
+        uint32_t s_ray = 0, s_iso = 1u, s_n = 0;
         if (!exhausted && n_idle >= kUnionRefillMin) {
             uint32_t mine;
             const bool got = chunk.take(n_idle, (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), head, n_items, n_idle, lane, mine);
@@ -1466,17 +1527,19 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                 const uint32_t grp = tile_order ? tile_order[at] : at; /* longest tiles of the previous launch first */
                 const uint32_t blk = in >> 6, ray = grp * 64u + (in & 63u);
                 if (ray < n_active) { /* the last group of 64 may be short */
-                    const float4 r = ray_dt[ray];
-                    sink.pix = ray_pix[ray];
-                    sink.ray = ray;
                     const uint32_t b0 = blk * block_isos, b1 = b0 + block_isos < iso_count ? b0 + block_isos : iso_count;
-                    UOPS::begin(U, stack, done, v, r, iso_begin + b0, b1 - b0);
-                    alive = true; popping = false; n_states = 0; n_rounds = 0;
+                    start = true; s_ray = ray; s_iso = iso_begin + b0; s_n = b1 - b0;
                     n_walks++;
                 }
             }
             exhausted = chunk.exhausted();
             if (exhausted && !tick_empty) tick_empty = __builtin_amdgcn_s_memrealtime();
+        }
+        if (start) {
+            sink.pix = ray_pix[s_ray];
+            sink.ray = s_ray;
+            UOPS::begin(U, stack, done, v, ray_dt[s_ray], s_iso, s_n);
+            alive = true; popping = false; n_states = 0; n_rounds = 0;
         }
         if (__ballot(alive) == 0ull) {
             if (exhausted) break;
@@ -1514,7 +1577,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     suspect = false; /* set where a box that is left does not share the front's exit plane */
                     if (++n_states > kUnionMaxStates) { /* safety valve: the iso values left are reported as errors */
                         vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); }, U.holes);
-                        sink.pend = false; sink.pend2 = false;
+                        sink.pend = false; sink.pend2 = false; sink.pend3 = false;
                         alive = false;
                         if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], n_rounds);
                     } else if (!x.in_root) {
@@ -1614,6 +1677,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(&info[0], (unsigned long long)s_cnt[kSweepCounters * n_k]);
+        if (blockIdx.x == 0 && tile_cost) *(tile_cost - kLptHeaderWords) = (n_active + 63u) >> 6;
         if (blockIdx.x == 0) { info[1] = n_active * n_blocks; info[5] = launch_seq; }
         atomicMax(&info[4], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
@@ -1646,11 +1710,18 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
 __global__ __launch_bounds__(64) void vr_k_union_fix(VrViewK v, const uint32_t *__restrict__ nodes, const float4 *__restrict__ ray_dt,
                                                      const uint32_t *__restrict__ ray_pix, const uint32_t *__restrict__ n_active_ptr,
                                                      const VrUnionRecord *__restrict__ list, uint32_t cap, uint32_t iso_begin,
-                                                     uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats)
+                                                     uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
+                                                     uint32_t stack_rows, uint32_t n_top)
 {
     uint32_t count = n_active_ptr[32];
     count = count < cap ? count : cap;
-    LdsStack<64u> st; /* dynamic LDS: [levels + 1][64] */
+    if (blockIdx.x >= count) return; /* nearly every block of nearly every launch */
+    LdsStack<64u> st; /* dynamic LDS: [levels + 1][64], then the top levels of the tree (these walks start at the root) */
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t *s_top = s_dyn + stack_rows * 64u;
+    for (uint32_t i = threadIdx.x; i < n_top; i += 64u) s_top[i] = nodes[i];
+    __syncthreads();
+    const TopFetch fetch(nodes, s_top, n_top, v.n_slots);
     /* one wave per record, a lane per iso value of its run */
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         const VrUnionRecord rec = list[i];
@@ -1667,7 +1738,7 @@ __global__ __launch_bounds__(64) void vr_k_union_fix(VrViewK v, const uint32_t *
             if (in_root) {
                 vr_lane_restart(A, st, v, __builtin_bit_cast(float, rec.t_bits), rec.cell);
                 for (;;) {
-                    const uint32_t go = vr_lane_descend(A, iso, GlobalFetch{ nodes }, st, 64u);
+                    const uint32_t go = vr_lane_descend(A, iso, fetch, st, 64u);
                     if (go == VR_GO_MORE) continue;
                     if (go == VR_GO_HIT) { hit = true; break; }
                     moves++;
@@ -1692,7 +1763,7 @@ __global__ __launch_bounds__(64) void vr_k_union_fix(VrViewK v, const uint32_t *
         }
     }
     /* the sweep's report ends where its last piece of work ends: the cut of the iso range is judged by that */
-    if (blockIdx.x < count && threadIdx.x == 0)
+    if (threadIdx.x == 0)
         atomicMax((unsigned long long *)(n_active_ptr + 16) + 4, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
@@ -1972,7 +2043,7 @@ struct Prepass {
 
 hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_count, uint32_t row_begin, uint32_t n_rows,
                           uint32_t center_out, uint8_t *d_rgb, vr_render_stats *d_stats, const VrTapsK &taps,
-                          uint32_t oob_word, void *workspace, Prepass &pp)
+                          uint32_t oob_word, void *workspace, Prepass &pp, uint32_t *tile_cost = nullptr, uint32_t *tile_order = nullptr)
 {
     const size_t n_pix = (size_t)view.width * n_rows;
     const uint32_t n_blocks = padded_tiles(view.width, n_rows) / (kSuper * kSuper);
@@ -1993,8 +2064,8 @@ hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
     if ((e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(vr_k_count, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt);
-    hipLaunchKernelGGL(vr_k_scan, dim3(1), dim3(1024), 0, stream, block_cnt, n_blocks, pp.n_active, pp.heads, iso_count, d_stats,
-                       (uint64_t)n_pix);
+    hipLaunchKernelGGL(vr_k_scan, dim3(tile_order ? 2 : 1), dim3(1024), 0, stream, block_cnt, n_blocks, pp.n_active, pp.heads, iso_count, d_stats,
+                       (uint64_t)n_pix, (uint32_t)((n_pix + 63u) / 64u), tile_cost, tile_order);
     hipLaunchKernelGGL(vr_k_compact, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt,
                        pp.ray_dt, pp.ray_pix);
     if (any_tap)
@@ -2074,33 +2145,29 @@ size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso
 size_t vr_pipeline_lpt_bytes(uint32_t width, uint32_t n_rows)
 {
     const size_t n_tiles = ((size_t)width * n_rows + 63u) / 64u + 1u;
-    return 2u * ((n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255); /* cost per tile, order of the tiles */
+    return 256u + 2u * ((n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255); /* header, length per tile, order of the tiles */
 }
 
 /* the tile costs and the tile order of the union kernel lie behind the pipeline workspace of the call */
 static void lpt_arrays(void *workspace, uint32_t width, uint32_t n_rows, uint32_t iso_count, uint32_t **cost, uint32_t **order)
 {
     char *w = (char *)workspace + ((vr_pipeline_workspace_bytes(width, n_rows, iso_count) + 255) & ~(size_t)255);
-    *cost = (uint32_t *)w;
-    *order = (uint32_t *)(w + vr_pipeline_lpt_bytes(width, n_rows) / 2u);
+    *cost = (uint32_t *)(w + 256u);
+    *order = (uint32_t *)(w + 256u + (vr_pipeline_lpt_bytes(width, n_rows) - 256u) / 2u);
 }
 
-/* Before a union launch: with the costs of the previous launch of the same call in place (lpt_mode 2) they become
- * the order of the tiles, else (1) the costs start at zero and the tiles keep the list's order; 0 = neither kept nor used. */
+/* For a union launch: with the lengths of the previous launch of the same call in place (lpt_mode 2) the pre-pass turns them
+ * into the order of the tiles (*order), else (1) the lengths start at zero and the tiles keep the list's order; 0 = neither
+ * kept nor used. */
 static hipError_t lpt_prepare(hipStream_t stream, int lpt_mode, void *workspace, const VrViewK &view, uint32_t n_rows, uint32_t iso_count,
-                              const uint32_t *n_active, uint32_t **order, uint32_t **cost)
+                              uint32_t **order, uint32_t **cost)
 {
     *order = nullptr; *cost = nullptr;
     if (lpt_mode == 0) return hipSuccess;
-    uint32_t *c, *o;
-    lpt_arrays(workspace, view.width, n_rows, iso_count, &c, &o);
-    *cost = c;
-    if (lpt_mode == 2) {
-        hipLaunchKernelGGL(vr_k_tile_order, dim3(1), dim3(1024), 0, stream, n_active, c, o);
-        *order = o;
-        return hipGetLastError();
-    }
-    return hipMemsetAsync(c, 0, vr_pipeline_lpt_bytes(view.width, n_rows) / 2u, stream);
+    lpt_arrays(workspace, view.width, n_rows, iso_count, cost, order);
+    if (lpt_mode == 2) return hipSuccess;
+    *order = nullptr;
+    return hipMemsetAsync(*cost - kLptHeaderWords, 0, 256u + (vr_pipeline_lpt_bytes(view.width, n_rows) - 256u) / 2u, stream);
 }
 
 /* levels of the tree a persistent block keeps in LDS: what is left of the CU's 160 KiB beside the path stacks (and
@@ -2172,8 +2239,10 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
      * need one walk per iso value) and node ranges nested along every path; else traversals shared between iso values */
     const bool use_union = sweep && variant != VR_KERNEL_SWEEP && !any_tap && ranges_nested;
     Prepass pp;
+    uint32_t *tile_order = nullptr, *tile_cost = nullptr;
+    if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, &tile_order, &tile_cost)) != hipSuccess) return e;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
-                            VR_FLAG_OOB << 24, workspace, pp)) != hipSuccess)
+                            VR_FLAG_OOB << 24, workspace, pp, tile_cost, tile_order)) != hipSuccess)
         return e;
     float4 *ray_dt = pp.ray_dt;
     uint32_t *ray_pix = pp.ray_pix, *n_active = pp.n_active, *heads = pp.heads;
@@ -2201,9 +2270,6 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                            (void *)&d_rgb, (void *)&d_stats, (void *)&slots, (void *)&taps };
     VrUnionRecord *except_list = (VrUnionRecord *)((char *)heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
     uint32_t except_cap = VR_UNION_EXCEPT_CAP;
-    uint32_t *tile_order = nullptr, *tile_cost = nullptr;
-    if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, n_active, &tile_order, &tile_cost)) != hipSuccess)
-        return e;
     void *args_union[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                            (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
@@ -2218,8 +2284,10 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
     if (use_union) { /* the few iso values whose own MOVE parted from the front's */
-        hipLaunchKernelGGL(vr_k_union_fix, dim3(2048), dim3(64), (size_t)stack_rows * 64u * sizeof(uint32_t), stream, view,
-                           d_nodes_prepared, ray_dt, ray_pix, n_active, except_list, except_cap, iso_begin, frame_pixels, d_rgb, d_stats);
+        const uint32_t fix_top = n_top < (1u << 13) ? n_top : (1u << 13); /* 32 KiB of top levels beside the wave's stack */
+        hipLaunchKernelGGL(vr_k_union_fix, dim3(2048), dim3(64), ((size_t)stack_rows * 64u + fix_top) * sizeof(uint32_t), stream, view,
+                           d_nodes_prepared, ray_dt, ray_pix, n_active, except_list, except_cap, iso_begin, frame_pixels, d_rgb, d_stats,
+                           stack_rows, fix_top);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (slots) {
@@ -2322,12 +2390,15 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
     /* a block of iso values: the sweep kernel with the wide lane code (traversals shared between iso values) */
     const bool sweep = variant == VR_KERNEL_SWEEP || variant == VR_KERNEL_UNION || (variant == VR_KERNEL_DEFAULT && iso_count >= 8u);
     Prepass pp;
-    if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
-                            VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp)) != hipSuccess)
-        return e;
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
+    const bool use_union = sweep && variant != VR_KERNEL_SWEEP && !any_tap && ranges_nested;
+    uint32_t *tile_order = nullptr, *tile_cost = nullptr;
+    if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, &tile_order, &tile_cost)) != hipSuccess) return e;
+    if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
+                            VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp, tile_cost, tile_order)) != hipSuccess)
+        return e;
     /* one traversal per ray for the whole iso range, under the same conditions as on narrow trees (vr_launch_render) */
-    if (sweep && variant != VR_KERNEL_SWEEP && !any_tap && ranges_nested) {
+    if (use_union) {
         const uint32_t n_top = 0u, stack_rows = VR_WIDE_MAX_DEPTH;
         const size_t lds = ((size_t)(stack_rows + 8u) * kTraceThreads + sweep_stat_words(iso_count)) * sizeof(uint32_t);
         if (lds > 160u * 1024u) return hipErrorInvalidValue;
@@ -2335,8 +2406,6 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
         VrUnionRecord *except_list = (VrUnionRecord *)((char *)pp.heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
         uint32_t except_cap = VR_UNION_EXCEPT_CAP;
-        uint32_t *tile_order = nullptr, *tile_cost = nullptr;
-        if ((e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, pp.n_active, &tile_order, &tile_cost)) != hipSuccess) return e;
         void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&stack_rows, (void *)&pp.ray_dt, (void *)&pp.ray_pix,
                          (void *)&pp.n_active, (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                          (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
