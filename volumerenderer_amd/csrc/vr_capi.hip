@@ -612,6 +612,21 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
                                 row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq,
                                 c->ranges_nested, lpt_mode));
     if (lpt_mode) c->last_union.have = true;
+    if (lpt_mode && std::getenv("VR_LPT_DEBUG")) { /* the lengths this launch left, as a histogram */
+        (void)hipStreamSynchronize(s);
+        const size_t off = (vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count) + 255) & ~(size_t)255;
+        uint32_t n_tiles = 0;
+        (void)hipMemcpy(&n_tiles, (char *)work + off, 4, hipMemcpyDeviceToHost);
+        std::vector<uint32_t> len(n_tiles);
+        (void)hipMemcpy(len.data(), (char *)work + off + 256, 4 * (size_t)n_tiles, hipMemcpyDeviceToHost);
+        uint32_t mx = 0; unsigned long long sum = 0;
+        for (uint32_t v : len) { mx = v > mx ? v : mx; sum += v; }
+        std::fprintf(stderr, "[lpt] mode %d tiles %u longest %u rounds mean %.1f;", lpt_mode, n_tiles, mx, n_tiles ? (double)sum / n_tiles : 0.0);
+        uint32_t h[16] = { 0 };
+        for (uint32_t v : len) h[mx ? (uint32_t)((uint64_t)v * 15u / mx) : 0u]++;
+        for (int i = 0; i < 16; i++) std::fprintf(stderr, " %u", h[i]);
+        std::fprintf(stderr, "\n");
+    }
     if (timing) c->ev_used += 2;
     if ((sweep_kernel || union_kernel) && !fixed_scratch) {
         c->info_off = vr_pipeline_info_offset(view->width, row_end - row_begin);

@@ -303,31 +303,26 @@ __global__ __launch_bounds__(kPreThreads) void vr_k_count(VrViewK v, uint32_t ro
 
 /* Order of the tiles (groups of 64 consecutive rays of the list) for a union launch that repeats the previous call:
  * longest first.  tile_cost holds, per tile, the largest number of rounds one lane spent on one of the tile's items in
- * the previous launch; the tiles are put into 16 classes by that length (relative to the longest) and the classes are
- * laid out one after the other, longest first, each in list order (tiles that lie next to each other in the image stay
- * together).  A launch ends with its longest fronts; starting them first shortens the time the grid spends draining.
- * Tiles behind the end of the list have length 0 and so come last, behind every tile of the list: the first
- * ceil(rays / 64) entries of the order are a permutation of the list's tiles.  Work of one block of 1024 threads (the
- * second block of vr_k_scan); leaves tile_cost at zero for the launch that follows. */
-constexpr uint32_t kLptClasses = 16;
+ * the previous launch.  A launch ends with its longest fronts, so they start first, and the queue ends with the
+ * shortest (a round takes about 10 us: twenty rounds more at the end of the queue are a fifth of a Skull sweep).
+ * Counting sort on the length (in steps of one round up to 255 rounds, of two up to 511, ...), longest first; inside a
+ * length the tiles come as the waves get to them.  Work of one block of 1024 threads (the second block of vr_k_scan);
+ * leaves tile_cost at zero for the launch that follows. */
+constexpr uint32_t kLptClasses = 256;
 constexpr uint32_t kLptHeaderWords = 64; /* in front of the lengths; word 0: tiles in the list of the launch that left them */
-__device__ __forceinline__ uint32_t lpt_class(uint32_t cost, float per_length)
-{
-    const uint32_t q = (uint32_t)((float)cost * per_length);
-    return (kLptClasses - 1u) - (q < kLptClasses - 1u ? q : kLptClasses - 1u);
-}
-constexpr uint32_t kLptPerLane = 16; /* lengths a lane reads at a time: the reads of a pass are in flight together */
+constexpr uint32_t kLptPerLane = 16; /* lengths a lane reads at a time: the reads are in flight together */
 __device__ void tile_order_block(uint32_t n_tiles, uint32_t *__restrict__ tile_cost, uint32_t *__restrict__ tile_order)
 {
     __shared__ uint32_t s_max[16];
-    __shared__ uint32_t s_cnt[kLptClasses * 16u]; /* [class][wave]: tiles, then where the wave's tiles of the class begin */
-    __shared__ uint32_t s_at[kLptClasses * 16u];
+    __shared__ uint32_t s_at[kLptClasses]; /* per class: tiles, then where the next tile of the class goes */
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per_wave = ((n_tiles + 15u) / 16u + 63u) & ~63u;
     const uint32_t w0 = wave * per_wave < n_tiles ? wave * per_wave : n_tiles;
     const uint32_t w1 = w0 + per_wave < n_tiles ? w0 + per_wave : n_tiles;
+    const bool one_chunk = w1 - w0 <= 64u * kLptPerLane; /* then the lengths stay in registers between the passes */
     uint32_t len[kLptPerLane];
     uint32_t mx = 0;
+    if (threadIdx.x < kLptClasses) s_at[threadIdx.x] = 0u;
     for (uint32_t g0 = w0; g0 < w1; g0 += 64u * kLptPerLane) {
 #pragma unroll
         for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[g] : 0u; }
@@ -340,32 +335,21 @@ __device__ void tile_order_block(uint32_t n_tiles, uint32_t *__restrict__ tile_c
     mx = 0;
 #pragma unroll
     for (uint32_t w = 0; w < 16u; w++) mx = s_max[w] > mx ? s_max[w] : mx;
-    const float per_length = (float)kLptClasses / ((float)mx + 1.0f);
-    uint32_t cnt[kLptClasses];
-#pragma unroll
-    for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] = 0;
+    const uint32_t bits = 32u - (uint32_t)__builtin_clz(mx | 1u), shift = bits > 8u ? bits - 8u : 0u; /* longest >> shift <= 255 */
     for (uint32_t g0 = w0; g0 < w1; g0 += 64u * kLptPerLane) {
-        if (w1 - w0 > 64u * kLptPerLane) { /* else the lengths of the wave's only chunk are still in registers */
+        if (!one_chunk) {
 #pragma unroll
             for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[g] : 0u; }
         }
 #pragma unroll
-        for (uint32_t j = 0; j < kLptPerLane; j++) {
-            if (g0 + j * 64u >= w1) break;
-            const uint32_t cls = g0 + j * 64u + lane < w1 ? lpt_class(len[j], per_length) : kLptClasses;
-#pragma unroll
-            for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] += (uint32_t)__popcll(__ballot(cls == c));
-        }
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (uint32_t c = 0; c < kLptClasses; c++) s_cnt[c * 16u + wave] = cnt[c];
+        for (uint32_t j = 0; j < kLptPerLane; j++)
+            if (g0 + j * 64u + lane < w1) atomicAdd(&s_at[(kLptClasses - 1u) - (len[j] >> shift)], 1u);
     }
     __syncthreads();
-    /* 256 counts to starting positions: class-major, waves in order inside a class (scan in waves 0-3, then their totals) */
+    /* counts to starting positions, longest class first (scan in waves 0-3, then their totals) */
     uint32_t mine = 0, incl = 0;
-    if (threadIdx.x < kLptClasses * 16u) {
-        mine = s_cnt[threadIdx.x];
+    if (threadIdx.x < kLptClasses) {
+        mine = s_at[threadIdx.x];
         incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -375,32 +359,24 @@ __device__ void tile_order_block(uint32_t n_tiles, uint32_t *__restrict__ tile_c
         if (lane == 63u) s_max[wave] = incl; /* every thread has read the lengths' maxima by now */
     }
     __syncthreads();
-    if (threadIdx.x < kLptClasses * 16u) {
+    if (threadIdx.x < kLptClasses) {
         uint32_t before = 0;
         for (uint32_t w = 0; w < wave; w++) before += s_max[w];
         s_at[threadIdx.x] = before + incl - mine;
     }
     __syncthreads();
-#pragma unroll
-    for (uint32_t c = 0; c < kLptClasses; c++) cnt[c] = s_at[c * 16u + wave];
-    const unsigned long long below = (1ull << lane) - 1ull;
     for (uint32_t g0 = w0; g0 < w1; g0 += 64u * kLptPerLane) {
-        if (w1 - w0 > 64u * kLptPerLane) {
+        if (!one_chunk) {
 #pragma unroll
             for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[g] : 0u; }
         }
 #pragma unroll
         for (uint32_t j = 0; j < kLptPerLane; j++) {
-            if (g0 + j * 64u >= w1) break;
             const uint32_t g = g0 + j * 64u + lane;
-            const uint32_t cls = g < w1 ? lpt_class(len[j], per_length) : kLptClasses;
-#pragma unroll
-            for (uint32_t c = 0; c < kLptClasses; c++) {
-                const unsigned long long b = __ballot(cls == c);
-                if (cls == c) tile_order[cnt[c] + (uint32_t)__popcll(b & below)] = g;
-                cnt[c] += (uint32_t)__popcll(b);
+            if (g < w1) {
+                tile_order[atomicAdd(&s_at[(kLptClasses - 1u) - (len[j] >> shift)], 1u)] = g;
+                tile_cost[g] = 0u;
             }
-            if (g < w1) tile_cost[g] = 0u;
         }
     }
 }
