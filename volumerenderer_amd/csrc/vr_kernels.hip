@@ -1477,15 +1477,30 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     bool alive = false, exhausted = false, popping = false, suspect = false;
     /* the front of a lane is finished: on with the iso values it has kept, if any, else the lane is idle (a macro, not
      * a lambda taking the two flags by reference: that kept them in scratch memory) */
+#ifdef VR_LPT_TICKS /* measuring build: an item's length in ticks of the 100 MHz clock instead of rounds */
+#define VR_ITEM_BEGIN() ((uint32_t)__builtin_amdgcn_s_memrealtime())
+#define VR_ITEM_ROUND(rounds) (rounds)
+#define VR_ITEM_LENGTH(rounds) ((uint32_t)__builtin_amdgcn_s_memrealtime() - (rounds))
+#else
+#define VR_ITEM_BEGIN() 0u
+#define VR_ITEM_ROUND(rounds) ((rounds) + 1u)
+#define VR_ITEM_LENGTH(rounds) (rounds)
+#endif
+#ifdef VR_LPT_PARTS /* measuring build: every front on its own, not the lane's whole item */
+#define VR_ITEM_PART() do { if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds)); n_rounds = VR_ITEM_BEGIN(); } while (0)
+#else
+#define VR_ITEM_PART() do { } while (0)
+#endif
 #define VR_FRONT_DONE()                                                                                     \
     do {                                                                                                    \
         if (sink.pend) {                                                                                    \
             UOPS::restart(U, stack, done, v, sink.pend_t, sink.pend_cell, sink.pend_runs);                  \
             sink.pend_shift();                                                                              \
             popping = false;                                                                                \
+            VR_ITEM_PART();                                                                                 \
         } else {                                                                                            \
             alive = false;                                                                                  \
-            if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], n_rounds);                                  \
+            if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds));                  \
         }                                                                                                   \
     } while (0)
 
@@ -1515,7 +1530,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             sink.pix = ray_pix[s_ray];
             sink.ray = s_ray;
             UOPS::begin(U, stack, done, v, ray_dt[s_ray], s_iso, s_n);
-            alive = true; popping = false; n_states = 0; n_rounds = 0;
+            alive = true; popping = false; n_states = 0; n_rounds = VR_ITEM_BEGIN();
         }
         if (__ballot(alive) == 0ull) {
             if (exhausted) break;
@@ -1538,7 +1553,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
         const uint32_t d_desc = wave_sum(alive && !popping ? 1u : 0u), d_fronts = (uint32_t)__popcll(__ballot(alive));
 #endif
         if (alive) {
-            n_rounds++;
+            n_rounds = VR_ITEM_ROUND(n_rounds);
             uint32_t go = VR_GO_MORE;
             if (!popping) go = UOPS::descend(U, fetch, stack, done, sink);
 #ifdef VR_DIAG
@@ -1555,7 +1570,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                         vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); }, U.holes);
                         sink.pend = false; sink.pend2 = false; sink.pend3 = false;
                         alive = false;
-                        if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], n_rounds);
+                        if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds));
                     } else if (!x.in_root) {
                         /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
                         const float t_new = U.L.t;
@@ -1627,7 +1642,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             if (lane == taker) {
                 sink.pix = g_pix; sink.ray = g_ray;
                 UOPS::restart(U, stack, done, v, g_t, g_cell, g_runs);
-                alive = true; popping = false; n_states = 0; n_rounds = 0;
+                alive = true; popping = false; n_states = 0; n_rounds = VR_ITEM_BEGIN();
             }
         }
     }
@@ -1680,6 +1695,10 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
 }
 
 #undef VR_FRONT_DONE
+#undef VR_ITEM_LENGTH
+#undef VR_ITEM_BEGIN
+#undef VR_ITEM_ROUND
+#undef VR_ITEM_PART
 
 /* The iso values that left the union walk: each is traced on its own from its own state (the checks and the MOVE of
  * the round that parked it are counted already, its escape helps of that MOVE come with the record). */
