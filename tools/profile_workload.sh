@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats of one bench workload, then its counter passes (HBM
 # traffic in runs of their own, no tracing options mixed in), and writes the two files bench.py and the judge read:
-#   gpurun_out/prof_<tag>/r02_stats_<workload>.csv   kernel stats of `bench.py --steps 10 --warmup 1 <args>`
+#   gpurun_out/prof_<tag>/r02_stats_<workload>.csv   kernel stats of `bench.py --steps 30 --warmup 1 <args>` (the first launch of a sweep has no tile order yet)
 #   gpurun_out/prof_<tag>/r02_pmc_<workload>.json    per-kernel counter means, the commit and the kernel-source fingerprint
 # Usage: tools/profile_workload.sh <tag> <commit> [bench args...]
 set -u
@@ -14,7 +14,11 @@ cd /tmp && export TMPDIR=/tmp
 # for the profiled runs below so that every traced launch runs with it
 cut=$(timeout -k 10 300 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-delivered "$@" 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline'].get('items_per_lane') or '')")
 if [ -n "$cut" ]; then export VR_SWEEP_ITEMS=$cut; echo "settled cut: $cut items per lane"; fi
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 10 --warmup 1 --settle 0 --no-cpu-baseline --no-host-delivered "$@" > $out/bench_trace.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 30 --warmup 1 --settle 0 --no-cpu-baseline --no-host-delivered "$@" > $out/bench_trace.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
+if [ -n "${PROFILE_TRACE_ONLY:-}" ]; then # only the kernel stats again (the counter summary of this workload stays)
+  f=$(find $out/trace -name "*kernel_stats.csv" | head -1); w=$(python3 -c "import json; print(json.load(open('$out/bench_trace.json'))['config']['workload'])")
+  cp $f $out/r02_stats_$w.csv; echo "$w: kernel stats only"; exit 0
+fi
 i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
             "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_LDS" \
