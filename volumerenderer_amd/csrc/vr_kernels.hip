@@ -309,7 +309,9 @@ __global__ __launch_bounds__(kPreThreads) void vr_k_count(VrViewK v, uint32_t ro
  * length the tiles come as the waves get to them.  Work of one block of 1024 threads (the second block of vr_k_scan);
  * leaves tile_cost at zero for the launch that follows. */
 constexpr uint32_t kLptClasses = 256;
-constexpr uint32_t kLptHeaderWords = 64; /* in front of the lengths; word 0: tiles in the list of the launch that left them */
+constexpr uint32_t kLptHeaderWords = 64; /* in front of the lengths; word 0: tiles in the list of the launch that left them,
+                                          * word 1: whether the pre-pass of this launch has made an order from them */
+constexpr uint32_t kLptMaxRaysPerLane = 8; /* lists beyond this many rays per lane of the grid keep their order */
 constexpr uint32_t kLptPerLane = 16; /* lengths a lane reads at a time: the reads are in flight together */
 __device__ void tile_order_block(uint32_t n_tiles, uint32_t *__restrict__ tile_cost, uint32_t *__restrict__ tile_order)
 {
@@ -386,11 +388,16 @@ __device__ void tile_order_block(uint32_t n_tiles, uint32_t *__restrict__ tile_c
 __global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, uint32_t n, uint32_t *__restrict__ n_active_out,
                                                   uint32_t *__restrict__ heads, uint32_t iso_count,
                                                   vr_render_stats *__restrict__ stats, uint64_t frame_pixels, uint32_t n_tiles,
-                                                  uint32_t *__restrict__ tile_cost, uint32_t *__restrict__ tile_order)
+                                                  uint32_t *__restrict__ tile_cost, uint32_t *__restrict__ tile_order,
+                                                  uint32_t order_max_tiles)
 {
     if (blockIdx.x == 1u) { /* launched only when the union kernel's tile order is wanted: it rides along on a block of its own */
         const uint32_t listed = *(tile_cost - kLptHeaderWords); /* the same list as this call's: same call */
-        tile_order_block(listed < n_tiles ? listed : n_tiles, tile_cost, tile_order);
+        /* a list of many rays per lane of the grid keeps its order: such a launch is not bound by how it ends (32 iso values
+         * of the 1024^3 gyroid at 4096^2, 48 rays per lane: 12.5 ms in list order, 12.6 longest first, plus 0.1 ms for the order) */
+        const bool wanted = listed <= order_max_tiles;
+        if (wanted) tile_order_block(listed < n_tiles ? listed : n_tiles, tile_cost, tile_order);
+        if (threadIdx.x == 0) *(tile_cost - kLptHeaderWords + 1) = wanted ? 1u : 0u; /* word 1: the order is there */
         return;
     }
     __shared__ uint32_t s_wave[16];
@@ -1468,6 +1475,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     typename UOPS::Exit x = {};
     WaveChunk chunk;
     uint32_t depth_k = 0, cell_before = 0, n_states = 0;
+    const bool ordered = tile_order && *(tile_cost - kLptHeaderWords + 1) != 0u;
+    /* lengths are kept only for lists the pre-pass would order (one atomic per item adds up on long lists) */
+    uint32_t *const length_out = tile_cost && ((n_active + 63u) >> 6) <= gridDim.x * (kTraceThreads / 64u) * kLptMaxRaysPerLane ? tile_cost : nullptr;
     uint32_t n_rounds = 0; /* rounds this lane has spent on its item: the item's length, kept per tile for the next launch's order */
 #ifdef VR_DIAG
     uint32_t d_round = 0;
@@ -1487,7 +1497,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
 #define VR_ITEM_LENGTH(rounds) (rounds)
 #endif
 #ifdef VR_LPT_PARTS /* measuring build: every front on its own, not the lane's whole item */
-#define VR_ITEM_PART() do { if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds)); n_rounds = VR_ITEM_BEGIN(); } while (0)
+#define VR_ITEM_PART() do { if (length_out) atomicMax(&length_out[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds)); n_rounds = VR_ITEM_BEGIN(); } while (0)
 #else
 #define VR_ITEM_PART() do { } while (0)
 #endif
@@ -1500,7 +1510,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             VR_ITEM_PART();                                                                                 \
         } else {                                                                                            \
             alive = false;                                                                                  \
-            if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds));                  \
+            if (length_out) atomicMax(&length_out[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds));                \
         }                                                                                                   \
     } while (0)
 
@@ -1515,7 +1525,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             const bool got = chunk.take(n_idle, (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), head, n_items, n_idle, lane, mine);
             if (!alive && got) {
                 const uint32_t at = mine / (64u * n_blocks), in = mine - at * 64u * n_blocks;
-                const uint32_t grp = tile_order ? tile_order[at] : at; /* longest tiles of the previous launch first */
+                const uint32_t grp = ordered ? tile_order[at] : at; /* longest tiles of the previous launch first */
                 const uint32_t blk = in >> 6, ray = grp * 64u + (in & 63u);
                 if (ray < n_active) { /* the last group of 64 may be short */
                     const uint32_t b0 = blk * block_isos, b1 = b0 + block_isos < iso_count ? b0 + block_isos : iso_count;
@@ -1570,7 +1580,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                         vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); }, U.holes);
                         sink.pend = false; sink.pend2 = false; sink.pend3 = false;
                         alive = false;
-                        if (tile_cost) atomicMax(&tile_cost[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds));
+                        if (length_out) atomicMax(&length_out[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds));
                     } else if (!x.in_root) {
                         /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
                         const float t_new = U.L.t;
@@ -2038,7 +2048,8 @@ struct Prepass {
 
 hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_count, uint32_t row_begin, uint32_t n_rows,
                           uint32_t center_out, uint8_t *d_rgb, vr_render_stats *d_stats, const VrTapsK &taps,
-                          uint32_t oob_word, void *workspace, Prepass &pp, uint32_t *tile_cost = nullptr, uint32_t *tile_order = nullptr)
+                          uint32_t oob_word, void *workspace, Prepass &pp, uint32_t *tile_cost = nullptr, uint32_t *tile_order = nullptr,
+                          uint32_t grid_lanes = 0)
 {
     const size_t n_pix = (size_t)view.width * n_rows;
     const uint32_t n_blocks = padded_tiles(view.width, n_rows) / (kSuper * kSuper);
@@ -2060,7 +2071,7 @@ hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_
     if ((e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(vr_k_count, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt);
     hipLaunchKernelGGL(vr_k_scan, dim3(tile_order ? 2 : 1), dim3(1024), 0, stream, block_cnt, n_blocks, pp.n_active, pp.heads, iso_count, d_stats,
-                       (uint64_t)n_pix, (uint32_t)((n_pix + 63u) / 64u), tile_cost, tile_order);
+                       (uint64_t)n_pix, (uint32_t)((n_pix + 63u) / 64u), tile_cost, tile_order, grid_lanes / 64u * kLptMaxRaysPerLane);
     hipLaunchKernelGGL(vr_k_compact, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt,
                        pp.ray_dt, pp.ray_pix);
     if (any_tap)
@@ -2237,7 +2248,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     uint32_t *tile_order = nullptr, *tile_cost = nullptr;
     if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, &tile_order, &tile_cost)) != hipSuccess) return e;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
-                            VR_FLAG_OOB << 24, workspace, pp, tile_cost, tile_order)) != hipSuccess)
+                            VR_FLAG_OOB << 24, workspace, pp, tile_cost, tile_order, (uint32_t)n_cus * kTraceBlocksPerCu * kTraceThreads)) != hipSuccess)
         return e;
     float4 *ray_dt = pp.ray_dt;
     uint32_t *ray_pix = pp.ray_pix, *n_active = pp.n_active, *heads = pp.heads;
@@ -2390,7 +2401,8 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
     uint32_t *tile_order = nullptr, *tile_cost = nullptr;
     if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, &tile_order, &tile_cost)) != hipSuccess) return e;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
-                            VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp, tile_cost, tile_order)) != hipSuccess)
+                            VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp, tile_cost, tile_order,
+                            (uint32_t)n_cus * kTraceBlocksPerCu * kTraceThreads)) != hipSuccess)
         return e;
     /* one traversal per ray for the whole iso range, under the same conditions as on narrow trees (vr_launch_render) */
     if (use_union) {
