@@ -390,7 +390,7 @@ def main():
             span = float(si.tick_end - si.tick_begin)
             info = {"walks_per_launch": int(si.walks), "items_per_launch": int(si.items),
                     "items_per_lane": int(si.items_per_lane), "cut_settled": bool(si.cut_settled), "settle_launches": main_settle,
-                    "list_runs": int(si.list_runs),
+                    "list_runs": int(si.list_runs), "tiles_longest_first": bool(si.tiles_longest_first),
                     "drain_frac": (si.tick_end - min(si.tick_queue_empty, si.tick_end)) / span,
                     "kernel_span_ms_gpu_clock": span / 1e5}
 

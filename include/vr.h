@@ -370,7 +370,8 @@ typedef struct vr_sweep_info {
     uint32_t items_per_lane; /* the cut of the iso range that launch ran with */
     uint32_t cut_settled;    /* 1 once the context has stopped trying other cuts on this workload */
     uint32_t list_runs;      /* union kernel: runs of iso values that its second kernel had to finish (normally 0) */
-    uint32_t reserved;
+    uint32_t tiles_longest_first; /* union kernel: 1 when the launch repeated the context's previous call and started its tiles of
+                                   * 64 rays in the order of the item lengths that call left (longest first), 0 = list order */
 } vr_sweep_info;
 int vr_sweep_info_read(vr_ctx *ctx, vr_sweep_info *out);
 

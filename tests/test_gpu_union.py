@@ -86,10 +86,14 @@ def test_union_kernel_repeated_calls_start_their_tiles_longest_first_with_the_sa
         pos, forw, up = oracle.main_camera(vox.shape)
         v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
         ref = run(rnd, v, W, 0, H, b, n, capi.KERNEL_PIPELINE)
+        si = capi.SweepInfo()
         for i in range(4):
             got = run(rnd, v, W, 0, H, b, n, capi.KERNEL_UNION)
             assert (got[1] == ref[1]).all(), (i, np.argwhere(got[1] != ref[1])[:8])
             assert bool(torch.equal(got[0], ref[0])), i
+            capi.check(L.vr_sweep_info_read(rnd.handle, C.byref(si)), "vr_sweep_info_read")
+            # the first call after a different one keeps list order, the repeats are ordered unless the list is long
+            assert si.tiles_longest_first == (1 if i > 0 and W < 4096 else 0), (W, i, si.tiles_longest_first)
         r0, r1 = H // 10, H - H // 8
         for i in range(2):
             part = run(rnd, v, W, r0, r1, b, n, capi.KERNEL_UNION)

@@ -50,6 +50,7 @@ struct vr_ctx {
     uint32_t last_ipl = 0; /* items per lane of the last sweep-kernel launch (0: one traversal per ray, nothing to cut) */
     bool ranges_nested = true; /* node ranges nested along every path: built trees always, uploaded ones when checked so */
     size_t info_off = 0; /* where the last sweep-kernel launch in d_work left its report; 0 = none yet */
+    size_t order_flag_off = 0; /* where its pre-pass said whether it ordered the tiles; 0 = it was not asked to */
     /* The sweep kernel's cut of the iso range, tuned per workload from its own reports.  Every sweep launch in the
      * context's scratch is tagged with a sequence number and followed by an asynchronous copy of its report into
      * page-locked memory; a later launch reads whatever report has arrived (it never waits).  Fewer, longer items
@@ -631,6 +632,7 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
     if ((sweep_kernel || union_kernel) && !fixed_scratch) {
         c->info_off = vr_pipeline_info_offset(view->width, row_end - row_begin);
         c->last_ipl = ipl;
+        c->order_flag_off = lpt_mode == 2 ? ((vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count) + 255) & ~(size_t)255) + 4u : 0u;
         if (c->tune.phase != 2 && !forced_ipl) /* the report follows the launch on its stream; the next launch reads it if it has arrived */
             VR_HIP(hipMemcpyAsync(c->h_info, (const char *)c->d_work + c->info_off, 48, hipMemcpyDeviceToHost, s));
     }
@@ -921,7 +923,9 @@ int vr_sweep_info_read(vr_ctx *c, vr_sweep_info *out)
     VR_HIP(hipStreamSynchronize(c->stream));
     VR_HIP(hipMemcpy(out, (const char *)c->d_work + c->info_off, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     VR_HIP(hipMemcpy(&out->list_runs, (const char *)c->d_work + c->info_off + 64, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    out->reserved = 0;
+    out->tiles_longest_first = 0;
+    if (c->order_flag_off)
+        VR_HIP(hipMemcpy(&out->tiles_longest_first, (const char *)c->d_work + c->order_flag_off, sizeof(uint32_t), hipMemcpyDeviceToHost));
     out->items_per_lane = c->last_ipl;
     out->cut_settled = c->tune.phase == 2 ? 1u : 0u;
     return VR_OK;
