@@ -463,6 +463,34 @@ def main():
             out["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
         if wide:
             out["build_ms_gpu"] = build_ms  # the host builder and the CPU oracle cannot run at this size
+        if world == 1 and info and (info.get("tiles_longest_first") or os.environ.get("VR_BENCH_FIRST_CALL")) and not main_plan.bands and args.in_flight == 1:
+            # The timed steps repeat one call, and from its second launch on such a call starts its tiles longest first.
+            # What a caller gets who renders a view once: the same call right after a different call on the context (a small
+            # one: 8 rows), one launch at a time, next to the repeated call timed the same way.
+            def one(first):
+                if first:
+                    with torch.cuda.stream(stream):
+                        capi.check(L.vr_render_device(r.handle, C.byref(view), I0, min(8, IN), 0, min(8, H), main_plan.d_rgb.data_ptr(),
+                                                      None, None, C.c_void_p(stream.cuda_stream)), "vr_render_device")
+                    torch.cuda.synchronize()
+                tot, n = C.c_double(), C.c_uint32()
+                capi.check(L.vr_timing_read(r.handle, C.byref(tot), C.byref(n)), "vr_timing_read")  # drop what came before
+                t0 = time.perf_counter()
+                with torch.cuda.stream(stream):
+                    main_plan.render(r, main_plan.d_rgb, main_plan.d_stats, C.c_void_p(stream.cuda_stream))
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t0
+                capi.check(L.vr_timing_read(r.handle, C.byref(tot), C.byref(n)), "vr_timing_read")
+                return dt1 * 1e3, tot.value / max(1, n.value)
+            capi.check(L.vr_set_timing(r.handle, 1), "vr_set_timing")
+            firsts = sorted(one(True) for _ in range(7))
+            repeats = sorted(one(False) for _ in range(7))
+            capi.check(L.vr_set_timing(r.handle, 0), "vr_set_timing")
+            out["first_call"] = {"ms_per_step": firsts[3][0], "kernel_ms": sorted(k for _, k in firsts)[3],
+                                 "value": rays_per_step / (firsts[3][0] * 1e-3) / 1e6,
+                                 "repeated_call_same_way_ms": repeats[3][0],
+                                 "note": "medians of 7 single launches, each synchronised; first = right after a different call on "
+                                         "the context (tiles in list order), repeated = the timed steps' call again"}
         if world == 1 and not wide and not args.no_host_delivered and IN * W * H * 3 <= (1 << 30):
             # the sweep as the reference's caller gets it: frames in host memory (page-locked), src/main.zig:119-135
             try:

@@ -84,6 +84,10 @@ struct vr_ctx {
         VrViewK view;
         uint32_t iso_begin = 0, iso_count = 0, row_begin = 0, row_end = 0;
         void *work = nullptr;
+        /* what lies behind the workspace: lengths kept by a launch with this cut of the iso range (0 = none, the words are
+         * zero), and an order made from the lengths of a launch with this cut (0 = none).  The lengths of a call repeat from
+         * launch to launch, so once the order comes from the cut in use nothing is kept or sorted any more. */
+        uint32_t lengths_ipl = 0, order_ipl = 0;
     } last_union;
     uint64_t tree_id = 0;                 /* changes with every upload / build */
     unsigned long long *h_info = nullptr; /* page-locked: walks, items, 3 ticks, sequence number */
@@ -510,6 +514,10 @@ static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, 
     if (cand) { ipl = sweep_cut_candidate(t.base, t.dir, t.step); t.n_launched++; }
     t.seq++;
     if (t.seq == 0) t.seq = 1;
+    /* The first launch of a workload does not count for the search (cold caches), and for a caller that renders a view once
+     * it is the only one: it runs with the cut that is best in list order (Skull, first call: 1.40 ms with 2 or 3 items per
+     * lane, 1.56 with 4; C60 1.11 / 1.13 / 1.15), the search starts from the base that finds the best cut of every volume. */
+    if (union_kernel && t.seq == 1u && t.phase == 0 && ipl > VR_UNION_ITEMS_FIRST) ipl = VR_UNION_ITEMS_FIRST;
     if (cand) t.last_seq = t.seq;
     t.ipl_of_seq[t.seq & 15u] = ipl;
     if (tune_debug) std::fprintf(stderr, "[sweep tune] launch %u: %u items per lane, phase %d\n", t.seq, ipl, t.phase);
@@ -599,7 +607,22 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         if (union_kernel && !lpt_off) {
             const bool same = u.have && u.tree_id == c->tree_id && u.work == work && same_view(u.view, k) &&
                               u.iso_begin == iso_begin && u.iso_count == iso_count && u.row_begin == row_begin && u.row_end == row_end;
-            lpt_mode = same ? 2 : 1;
+            if (!same) { u.lengths_ipl = 0; u.order_ipl = 0; }
+            if (u.order_ipl == ipl) {
+                lpt_mode = VR_LPT_USE;
+            } else if (u.lengths_ipl == ipl) {
+                lpt_mode = VR_LPT_SORT | VR_LPT_USE;
+                u.order_ipl = ipl; u.lengths_ipl = 0;
+            } else if (u.lengths_ipl) { /* lengths of another cut: good enough to order by, and this cut's are kept */
+                lpt_mode = VR_LPT_SORT | VR_LPT_USE | VR_LPT_RECORD;
+                u.order_ipl = u.lengths_ipl; u.lengths_ipl = ipl;
+            } else if (u.order_ipl) {   /* an order from another cut, no lengths */
+                lpt_mode = VR_LPT_USE | VR_LPT_RECORD;
+                u.lengths_ipl = ipl;
+            } else {
+                lpt_mode = VR_LPT_RECORD | VR_LPT_CLEAR;
+                u.lengths_ipl = ipl;
+            }
             u.tree_id = c->tree_id; u.view = k;
             u.iso_begin = iso_begin; u.iso_count = iso_count; u.row_begin = row_begin; u.row_end = row_end; u.work = work;
         }
@@ -618,8 +641,10 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         const size_t off = (vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count) + 255) & ~(size_t)255;
         uint32_t n_tiles = 0;
         (void)hipMemcpy(&n_tiles, (char *)work + off, 4, hipMemcpyDeviceToHost);
+        n_tiles = n_tiles < VR_LPT_MAX_TILES ? n_tiles : 0u;
         std::vector<uint32_t> len(n_tiles);
-        (void)hipMemcpy(len.data(), (char *)work + off + 256, 4 * (size_t)n_tiles, hipMemcpyDeviceToHost);
+        if (n_tiles)
+            (void)hipMemcpy2D(len.data(), 4, (char *)work + off + 256, VR_LPT_STRIDE_WORDS * 4u, 4, n_tiles, hipMemcpyDeviceToHost);
         uint32_t mx = 0; unsigned long long sum = 0;
         for (uint32_t v : len) { mx = v > mx ? v : mx; sum += v; }
         std::fprintf(stderr, "[lpt] mode %d tiles %u longest %u rounds mean %.1f;", lpt_mode, n_tiles, mx, n_tiles ? (double)sum / n_tiles : 0.0);
@@ -632,7 +657,7 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
     if ((sweep_kernel || union_kernel) && !fixed_scratch) {
         c->info_off = vr_pipeline_info_offset(view->width, row_end - row_begin);
         c->last_ipl = ipl;
-        c->order_flag_off = lpt_mode == 2 ? ((vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count) + 255) & ~(size_t)255) + 4u : 0u;
+        c->order_flag_off = (lpt_mode & VR_LPT_USE) ? ((vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count) + 255) & ~(size_t)255) + 4u : 0u;
         if (c->tune.phase != 2 && !forced_ipl) /* the report follows the launch on its stream; the next launch reads it if it has arrived */
             VR_HIP(hipMemcpyAsync(c->h_info, (const char *)c->d_work + c->info_off, 48, hipMemcpyDeviceToHost, s));
     }

@@ -36,6 +36,8 @@ enum {
 #define VR_SWEEP_ITEMS_DEFAULT 8u
 /* (ray, iso block) items per lane of the grid that the union kernel starts from for long sweeps (tuned per workload) */
 #define VR_UNION_ITEMS_DEFAULT 4u
+/* ... and what the first launch of a workload runs with (the tiles of a first call are in list order: fewer, longer items) */
+#define VR_UNION_ITEMS_FIRST 3u
 /* iso values per call from which the default is the kernel with one traversal per ray for all of them */
 #define VR_UNION_MIN_ISOS 8u
 /* runs of iso values that may leave the union walks of one call (a few per thousand rays do) */
@@ -51,8 +53,16 @@ size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso
 
 /* Behind the pipeline workspace of a call (rounded up to 256 bytes): what the kernel with one traversal per ray keeps from
  * launch to launch of the same call -- per tile of 64 rays the length of its longest item, and the order of the tiles made
- * from it.  lpt_mode of the launchers: 0 = the arrays are not there (nothing kept, list order), 1 = keep the lengths of
- * this launch, 2 = the lengths of the previous launch of this very call are in place: longest tiles first, keep again. */
+ * from it (longest first).  lpt_mode of the launchers is 0 (the arrays are not there: nothing kept, list order) or a sum of: */
+enum {
+    VR_LPT_RECORD = 1, /* the launch keeps the lengths of its items (they start from what is there: zero after a sort or a clear) */
+    VR_LPT_SORT = 2,   /* the lengths of an earlier launch of this very call are in place: the pre-pass makes the order from them
+                        * and leaves them at zero */
+    VR_LPT_USE = 4,    /* the tiles are handed out in the order that is in place (after the sort, if there is one) */
+    VR_LPT_CLEAR = 8   /* the lengths are set to zero before the launch */
+};
+#define VR_LPT_STRIDE_WORDS 64u   /* a tile's length lies in a 256-byte line of its own */
+#define VR_LPT_MAX_TILES 32768u  /* lists of more tiles are neither measured nor ordered */
 size_t vr_pipeline_lpt_bytes(uint32_t width, uint32_t n_rows);
 
 /* Byte offset, inside the pipeline workspace of a call, of the sweep kernel's 40-byte report (vr_sweep_info). */

@@ -312,6 +312,16 @@ constexpr uint32_t kLptClasses = 256;
 constexpr uint32_t kLptHeaderWords = 64; /* in front of the lengths; word 0: tiles in the list of the launch that left them,
                                           * word 1: whether the pre-pass of this launch has made an order from them */
 constexpr uint32_t kLptMaxRaysPerLane = 8; /* lists beyond this many rays per lane of the grid keep their order */
+/* A tile's length has a 256-byte line of its own: the items that end at the same time are those of neighbouring tiles of the
+ * list, and their atomics on neighbouring words of a few lines held up every wave behind them (a first call of the Skull
+ * sweep cut into 4 blocks per ray: 1.78 ms with packed words against 1.55 without keeping lengths; 8 blocks: 2.96 against 1.86) */
+constexpr uint32_t kLptStride = VR_LPT_STRIDE_WORDS;
+/* the longest list (in tiles) that is ordered: 8 rays per lane of the grid, and what the array behind the workspace holds */
+__host__ __device__ inline uint32_t lpt_max_tiles(uint32_t grid_lanes)
+{
+    const uint32_t by_grid = grid_lanes / 64u * kLptMaxRaysPerLane;
+    return by_grid < VR_LPT_MAX_TILES ? by_grid : VR_LPT_MAX_TILES;
+}
 constexpr uint32_t kLptPerLane = 16; /* lengths a lane reads at a time: the reads are in flight together */
 __device__ void tile_order_block(uint32_t n_tiles, uint32_t *__restrict__ tile_cost, uint32_t *__restrict__ tile_order)
 {
@@ -327,7 +337,7 @@ __device__ void tile_order_block(uint32_t n_tiles, uint32_t *__restrict__ tile_c
     if (threadIdx.x < kLptClasses) s_at[threadIdx.x] = 0u;
     for (uint32_t g0 = w0; g0 < w1; g0 += 64u * kLptPerLane) {
 #pragma unroll
-        for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[g] : 0u; }
+        for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[(size_t)g * kLptStride] : 0u; }
 #pragma unroll
         for (uint32_t j = 0; j < kLptPerLane; j++) mx = len[j] > mx ? len[j] : mx;
     }
@@ -341,7 +351,7 @@ __device__ void tile_order_block(uint32_t n_tiles, uint32_t *__restrict__ tile_c
     for (uint32_t g0 = w0; g0 < w1; g0 += 64u * kLptPerLane) {
         if (!one_chunk) {
 #pragma unroll
-            for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[g] : 0u; }
+            for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[(size_t)g * kLptStride] : 0u; }
         }
 #pragma unroll
         for (uint32_t j = 0; j < kLptPerLane; j++)
@@ -370,14 +380,14 @@ __device__ void tile_order_block(uint32_t n_tiles, uint32_t *__restrict__ tile_c
     for (uint32_t g0 = w0; g0 < w1; g0 += 64u * kLptPerLane) {
         if (!one_chunk) {
 #pragma unroll
-            for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[g] : 0u; }
+            for (uint32_t j = 0; j < kLptPerLane; j++) { const uint32_t g = g0 + j * 64u + lane; len[j] = g < w1 ? tile_cost[(size_t)g * kLptStride] : 0u; }
         }
 #pragma unroll
         for (uint32_t j = 0; j < kLptPerLane; j++) {
             const uint32_t g = g0 + j * 64u + lane;
             if (g < w1) {
                 tile_order[atomicAdd(&s_at[(kLptClasses - 1u) - (len[j] >> shift)], 1u)] = g;
-                tile_cost[g] = 0u;
+                tile_cost[(size_t)g * kLptStride] = 0u;
             }
         }
     }
@@ -1432,7 +1442,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     const uint32_t *__restrict__ ray_pix, const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ head, uint32_t iso_begin,
     uint32_t iso_count, uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
     VrUnionRecord *__restrict__ except_list, uint32_t except_cap, uint32_t items_per_lane, uint32_t launch_seq,
-    const uint32_t *__restrict__ tile_order, uint32_t *__restrict__ tile_cost)
+    const uint32_t *__restrict__ tile_order, uint32_t *__restrict__ tile_cost, uint32_t keep_lengths)
 {
     /* dynamic LDS: [path stacks][check sums and counters as in vr_k_sweep][done bits: 8 x kTraceThreads words][top node words] */
     extern __shared__ uint32_t s_dyn[];
@@ -1477,7 +1487,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     uint32_t depth_k = 0, cell_before = 0, n_states = 0;
     const bool ordered = tile_order && *(tile_cost - kLptHeaderWords + 1) != 0u;
     /* lengths are kept only for lists the pre-pass would order (one atomic per item adds up on long lists) */
-    uint32_t *const length_out = tile_cost && ((n_active + 63u) >> 6) <= gridDim.x * (kTraceThreads / 64u) * kLptMaxRaysPerLane ? tile_cost : nullptr;
+    uint32_t *const length_out = tile_cost && keep_lengths && ((n_active + 63u) >> 6) <= lpt_max_tiles(gridDim.x * kTraceThreads) ? tile_cost : nullptr;
     uint32_t n_rounds = 0; /* rounds this lane has spent on its item: the item's length, kept per tile for the next launch's order */
 #ifdef VR_DIAG
     uint32_t d_round = 0;
@@ -1497,7 +1507,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
 #define VR_ITEM_LENGTH(rounds) (rounds)
 #endif
 #ifdef VR_LPT_PARTS /* measuring build: every front on its own, not the lane's whole item */
-#define VR_ITEM_PART() do { if (length_out) atomicMax(&length_out[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds)); n_rounds = VR_ITEM_BEGIN(); } while (0)
+#define VR_ITEM_PART() do { if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], VR_ITEM_LENGTH(n_rounds)); n_rounds = VR_ITEM_BEGIN(); } while (0)
 #else
 #define VR_ITEM_PART() do { } while (0)
 #endif
@@ -1510,7 +1520,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             VR_ITEM_PART();                                                                                 \
         } else {                                                                                            \
             alive = false;                                                                                  \
-            if (length_out) atomicMax(&length_out[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds));                \
+            if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], VR_ITEM_LENGTH(n_rounds)); \
         }                                                                                                   \
     } while (0)
 
@@ -1580,7 +1590,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                         vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); }, U.holes);
                         sink.pend = false; sink.pend2 = false; sink.pend3 = false;
                         alive = false;
-                        if (length_out) atomicMax(&length_out[sink.ray >> 6], VR_ITEM_LENGTH(n_rounds));
+                        if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], VR_ITEM_LENGTH(n_rounds));
                     } else if (!x.in_root) {
                         /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
                         const float t_new = U.L.t;
@@ -2071,7 +2081,7 @@ hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_
     if ((e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(vr_k_count, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt);
     hipLaunchKernelGGL(vr_k_scan, dim3(tile_order ? 2 : 1), dim3(1024), 0, stream, block_cnt, n_blocks, pp.n_active, pp.heads, iso_count, d_stats,
-                       (uint64_t)n_pix, (uint32_t)((n_pix + 63u) / 64u), tile_cost, tile_order, grid_lanes / 64u * kLptMaxRaysPerLane);
+                       (uint64_t)n_pix, (uint32_t)((n_pix + 63u) / 64u), tile_cost, tile_order, lpt_max_tiles(grid_lanes));
     hipLaunchKernelGGL(vr_k_compact, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt,
                        pp.ray_dt, pp.ray_pix);
     if (any_tap)
@@ -2148,32 +2158,41 @@ size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso
     return bytes;
 }
 
-size_t vr_pipeline_lpt_bytes(uint32_t width, uint32_t n_rows)
+static size_t lpt_tiles(uint32_t width, uint32_t n_rows)
 {
     const size_t n_tiles = ((size_t)width * n_rows + 63u) / 64u + 1u;
-    return 256u + 2u * ((n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255); /* header, length per tile, order of the tiles */
+    return n_tiles < VR_LPT_MAX_TILES ? n_tiles : VR_LPT_MAX_TILES; /* longer lists are neither measured nor ordered */
 }
 
-/* the tile costs and the tile order of the union kernel lie behind the pipeline workspace of the call */
+size_t vr_pipeline_lpt_bytes(uint32_t width, uint32_t n_rows)
+{
+    const size_t n = lpt_tiles(width, n_rows);
+    return 256u + n * VR_LPT_STRIDE_WORDS * sizeof(uint32_t) + ((n * sizeof(uint32_t) + 255) & ~(size_t)255); /* header, lengths, order */
+}
+
+/* the tile lengths and the tile order of the union kernel lie behind the pipeline workspace of the call */
 static void lpt_arrays(void *workspace, uint32_t width, uint32_t n_rows, uint32_t iso_count, uint32_t **cost, uint32_t **order)
 {
     char *w = (char *)workspace + ((vr_pipeline_workspace_bytes(width, n_rows, iso_count) + 255) & ~(size_t)255);
     *cost = (uint32_t *)(w + 256u);
-    *order = (uint32_t *)(w + 256u + (vr_pipeline_lpt_bytes(width, n_rows) - 256u) / 2u);
+    *order = (uint32_t *)(w + 256u + lpt_tiles(width, n_rows) * VR_LPT_STRIDE_WORDS * sizeof(uint32_t));
 }
 
-/* For a union launch: with the lengths of the previous launch of the same call in place (lpt_mode 2) the pre-pass turns them
- * into the order of the tiles (*order), else (1) the lengths start at zero and the tiles keep the list's order; 0 = neither
- * kept nor used. */
+/* For a union launch, from the bits of lpt_mode (vr_internal.h): where the lengths and the order lie, whether the pre-pass
+ * sorts (*sort_into), whether the kernel follows the order (*order) and keeps lengths (*keep); clears the lengths when asked. */
 static hipError_t lpt_prepare(hipStream_t stream, int lpt_mode, void *workspace, const VrViewK &view, uint32_t n_rows, uint32_t iso_count,
-                              uint32_t **order, uint32_t **cost)
+                              uint32_t **order, uint32_t **sort_into, uint32_t **cost, uint32_t *keep)
 {
-    *order = nullptr; *cost = nullptr;
+    *order = nullptr; *sort_into = nullptr; *cost = nullptr; *keep = 0u;
     if (lpt_mode == 0) return hipSuccess;
-    lpt_arrays(workspace, view.width, n_rows, iso_count, cost, order);
-    if (lpt_mode == 2) return hipSuccess;
-    *order = nullptr;
-    return hipMemsetAsync(*cost - kLptHeaderWords, 0, 256u + (vr_pipeline_lpt_bytes(view.width, n_rows) - 256u) / 2u, stream);
+    uint32_t *o;
+    lpt_arrays(workspace, view.width, n_rows, iso_count, cost, &o);
+    if (lpt_mode & VR_LPT_USE) *order = o;
+    if (lpt_mode & VR_LPT_SORT) *sort_into = o;
+    *keep = (lpt_mode & VR_LPT_RECORD) ? 1u : 0u;
+    if (lpt_mode & VR_LPT_CLEAR)
+        return hipMemsetAsync(*cost - kLptHeaderWords, 0, 256u + lpt_tiles(view.width, n_rows) * VR_LPT_STRIDE_WORDS * sizeof(uint32_t), stream);
+    return hipSuccess;
 }
 
 /* levels of the tree a persistent block keeps in LDS: what is left of the CU's 160 KiB beside the path stacks (and
@@ -2245,10 +2264,11 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
      * need one walk per iso value) and node ranges nested along every path; else traversals shared between iso values */
     const bool use_union = sweep && variant != VR_KERNEL_SWEEP && !any_tap && ranges_nested;
     Prepass pp;
-    uint32_t *tile_order = nullptr, *tile_cost = nullptr;
-    if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, &tile_order, &tile_cost)) != hipSuccess) return e;
+    uint32_t *tile_order = nullptr, *sort_into = nullptr, *tile_cost = nullptr, keep_lengths = 0;
+    if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, &tile_order, &sort_into, &tile_cost, &keep_lengths)) != hipSuccess)
+        return e;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
-                            VR_FLAG_OOB << 24, workspace, pp, tile_cost, tile_order, (uint32_t)n_cus * kTraceBlocksPerCu * kTraceThreads)) != hipSuccess)
+                            VR_FLAG_OOB << 24, workspace, pp, tile_cost, sort_into, (uint32_t)n_cus * kTraceBlocksPerCu * kTraceThreads)) != hipSuccess)
         return e;
     float4 *ray_dt = pp.ray_dt;
     uint32_t *ray_pix = pp.ray_pix, *n_active = pp.n_active, *heads = pp.heads;
@@ -2279,7 +2299,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     void *args_union[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                            (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
-                           (void *)&launch_seq, (void *)&tile_order, (void *)&tile_cost };
+                           (void *)&launch_seq, (void *)&tile_order, (void *)&tile_cost, (void *)&keep_lengths };
     void **args = use_union ? args_union : (sweep ? args_sweep : args_trace);
     const void *fn = use_union ? (const void *)vr_k_union<UnionNarrow>
                    : sweep ? (any_tap ? (const void *)vr_k_sweep<true, SweepNarrow> : (const void *)vr_k_sweep<false, SweepNarrow>)
@@ -2398,10 +2418,11 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
     Prepass pp;
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
     const bool use_union = sweep && variant != VR_KERNEL_SWEEP && !any_tap && ranges_nested;
-    uint32_t *tile_order = nullptr, *tile_cost = nullptr;
-    if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, &tile_order, &tile_cost)) != hipSuccess) return e;
+    uint32_t *tile_order = nullptr, *sort_into = nullptr, *tile_cost = nullptr, keep_lengths = 0;
+    if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, &tile_order, &sort_into, &tile_cost, &keep_lengths)) != hipSuccess)
+        return e;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
-                            VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp, tile_cost, tile_order,
+                            VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp, tile_cost, sort_into,
                             (uint32_t)n_cus * kTraceBlocksPerCu * kTraceThreads)) != hipSuccess)
         return e;
     /* one traversal per ray for the whole iso range, under the same conditions as on narrow trees (vr_launch_render) */
@@ -2416,7 +2437,7 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&stack_rows, (void *)&pp.ray_dt, (void *)&pp.ray_pix,
                          (void *)&pp.n_active, (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                          (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
-                         (void *)&launch_seq, (void *)&tile_order, (void *)&tile_cost };
+                         (void *)&launch_seq, (void *)&tile_order, (void *)&tile_cost, (void *)&keep_lengths };
         if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
         if ((e = hipLaunchKernel((const void *)vr_k_union<UnionWide>, dim3(blocks), dim3(kTraceThreads), args, lds, stream)) != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
