@@ -8,7 +8,7 @@ rays count, including the ones that miss the volume -- the reference's ms/frame 
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling auto|weak|strong] [--shard bands|rows|iso]
                     [--gather] [--no-extras] [--in-flight F] [--kernel V] [--width PX]
-                    [--volume skull|c60|standin256|gyroid1024] [--iso-begin B] [--iso-count N] [--no-cpu-baseline]
+                    [--volume skull|c60|standin256|gyroid1024] [--iso-begin B] [--iso-count N] [--no-cpu-baseline] [--no-first-call]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`
 (one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE from the environment).  The path shards with no
@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--iso-begin", type=int, default=0)
     ap.add_argument("--iso-count", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-first-call", action="store_true", help="profiling runs: every launch of the run is a timed-step launch")
     ap.add_argument("--no-host-delivered", action="store_true",
                     help="skip the host-delivered leg (profiling runs: its shorter launches would mix into the kernel statistics)")
     ap.add_argument("--settle", type=int, default=24,
@@ -463,7 +464,8 @@ def main():
             out["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
         if wide:
             out["build_ms_gpu"] = build_ms  # the host builder and the CPU oracle cannot run at this size
-        if world == 1 and info and (info.get("tiles_longest_first") or os.environ.get("VR_BENCH_FIRST_CALL")) and not main_plan.bands and args.in_flight == 1:
+        if (world == 1 and info and (info.get("tiles_longest_first") or os.environ.get("VR_BENCH_FIRST_CALL")) and not main_plan.bands
+                and args.in_flight == 1 and not args.no_first_call):
             # The timed steps repeat one call, and from its second launch on such a call starts its tiles longest first.
             # What a caller gets who renders a view once: the same call right after a different call on the context (a small
             # one: 8 rows), one launch at a time, next to the repeated call timed the same way.
