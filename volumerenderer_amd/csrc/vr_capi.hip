@@ -4,6 +4,8 @@
  * stand in for raytrace.renderImage (src/raytrace.zig:11-106) and the iso loop of the reference
  * driver (src/main.zig:111-138).
  */
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -620,7 +622,8 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
                 lpt_mode = VR_LPT_USE | VR_LPT_RECORD;
                 u.lengths_ipl = ipl;
             } else {
-                lpt_mode = VR_LPT_RECORD | VR_LPT_CLEAR;
+                static const bool chord_off = std::getenv("VR_UNION_CHORD") && std::atoi(std::getenv("VR_UNION_CHORD")) == 0; /* A/B runs */
+                lpt_mode = VR_LPT_RECORD | VR_LPT_CLEAR | (chord_off ? 0 : VR_LPT_CHORD | VR_LPT_USE);
                 u.lengths_ipl = ipl;
             }
             u.tree_id = c->tree_id; u.view = k;
@@ -652,6 +655,41 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         for (uint32_t v : len) h[mx ? (uint32_t)((uint64_t)v * 15u / mx) : 0u]++;
         for (int i = 0; i < 16; i++) std::fprintf(stderr, " %u", h[i]);
         std::fprintf(stderr, "\n");
+        if (std::getenv("VR_LPT_CHORD") && n_tiles && mx) { /* experiment: how well does the chord through the root box predict a tile's length? */
+            std::vector<float> rays(4 * (size_t)n_tiles * 64u, 0.0f);
+            (void)hipMemcpy(rays.data(), work, rays.size() * 4u, hipMemcpyDeviceToHost);
+            std::vector<float> chord(n_tiles, 0.0f);
+            const float o[3] = { k.ox, k.oy, k.oz }, dim[3] = { (float)k.rdx, (float)k.rdy, (float)k.rdz };
+            for (uint32_t t = 0; t < n_tiles; t++)
+                for (uint32_t l = 0; l < 64u; l++) {
+                    const float *r = &rays[4 * ((size_t)t * 64u + l)];
+                    float te = 1e30f;
+                    for (int a = 0; a < 3; a++) {
+                        if (r[a] > 1e-8f) te = std::fmin(te, (dim[a] - o[a]) / r[a]);
+                        else if (r[a] < -1e-8f) te = std::fmin(te, (0.0f - o[a]) / r[a]);
+                    }
+                    const float c = te - r[3];
+                    if (c > chord[t] && c < 1e6f) chord[t] = c;
+                }
+            auto ranks = [&](std::vector<double> v) { std::vector<uint32_t> idx(v.size()); for (uint32_t i = 0; i < v.size(); i++) idx[i] = i;
+                std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return v[a] < v[b]; });
+                std::vector<double> rk(v.size()); for (uint32_t i = 0; i < v.size(); i++) rk[idx[i]] = i; return rk; };
+            std::vector<double> a(n_tiles), b(n_tiles), pos(n_tiles);
+            for (uint32_t t = 0; t < n_tiles; t++) { a[t] = chord[t]; b[t] = len[t]; pos[t] = -(double)t; }
+            auto corr = [&](const std::vector<double> &x, const std::vector<double> &y) { double mx2 = 0, my = 0; for (size_t i = 0; i < x.size(); i++) { mx2 += x[i]; my += y[i]; }
+                mx2 /= x.size(); my /= y.size(); double sxy = 0, sxx = 0, syy = 0; for (size_t i = 0; i < x.size(); i++) { sxy += (x[i] - mx2) * (y[i] - my); sxx += (x[i] - mx2) * (x[i] - mx2); syy += (y[i] - my) * (y[i] - my); }
+                return sxy / std::sqrt(sxx * syy); };
+            std::fprintf(stderr, "[lpt] rank correlation with the lengths: chord %.3f, list position (earlier = longer) %.3f\n", corr(ranks(a), ranks(b)), corr(ranks(pos), ranks(b)));
+            /* where do the 5 %% longest tiles lie in either order? */
+            std::vector<uint32_t> by_len(n_tiles), by_chord(n_tiles);
+            for (uint32_t t = 0; t < n_tiles; t++) by_len[t] = by_chord[t] = t;
+            std::sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return len[x] > len[y]; });
+            std::sort(by_chord.begin(), by_chord.end(), [&](uint32_t x, uint32_t y) { return chord[x] > chord[y]; });
+            std::vector<uint32_t> chord_pos(n_tiles); for (uint32_t i = 0; i < n_tiles; i++) chord_pos[by_chord[i]] = i;
+            const uint32_t top = n_tiles / 20u; double mean_list = 0, mean_chord = 0; uint32_t worst_list = 0, worst_chord = 0;
+            for (uint32_t i = 0; i < top; i++) { const uint32_t t = by_len[i]; mean_list += t; mean_chord += chord_pos[t]; worst_list = t > worst_list ? t : worst_list; worst_chord = chord_pos[t] > worst_chord ? chord_pos[t] : worst_chord; }
+            std::fprintf(stderr, "[lpt] the %u longest tiles: mean / last position in list order %.0f / %u, in chord order %.0f / %u (of %u)\n", top, mean_list / top, worst_list, mean_chord / top, worst_chord, n_tiles);
+        }
     }
     if (timing) c->ev_used += 2;
     if ((sweep_kernel || union_kernel) && !fixed_scratch) {
@@ -949,8 +987,11 @@ int vr_sweep_info_read(vr_ctx *c, vr_sweep_info *out)
     VR_HIP(hipMemcpy(out, (const char *)c->d_work + c->info_off, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     VR_HIP(hipMemcpy(&out->list_runs, (const char *)c->d_work + c->info_off + 64, sizeof(uint32_t), hipMemcpyDeviceToHost));
     out->tiles_longest_first = 0;
-    if (c->order_flag_off)
-        VR_HIP(hipMemcpy(&out->tiles_longest_first, (const char *)c->d_work + c->order_flag_off, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (c->order_flag_off) { /* 1 = ordered by item lengths; 2 (a first call's order by chords) is not reported as that */
+        uint32_t made_from = 0;
+        VR_HIP(hipMemcpy(&made_from, (const char *)c->d_work + c->order_flag_off, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        out->tiles_longest_first = made_from == 1u ? 1u : 0u;
+    }
     out->items_per_lane = c->last_ipl;
     out->cut_settled = c->tune.phase == 2 ? 1u : 0u;
     return VR_OK;

@@ -59,7 +59,9 @@ enum {
     VR_LPT_SORT = 2,   /* the lengths of an earlier launch of this very call are in place: the pre-pass makes the order from them
                         * and leaves them at zero */
     VR_LPT_USE = 4,    /* the tiles are handed out in the order that is in place (after the sort, if there is one) */
-    VR_LPT_CLEAR = 8   /* the lengths are set to zero before the launch */
+    VR_LPT_CLEAR = 8,  /* the lengths are set to zero before the launch */
+    VR_LPT_CHORD = 16  /* a first call: the pre-pass leaves every tile's longest chord through the volume in the (cleared) words,
+                        * makes the order from them and leaves them at zero (with VR_LPT_USE: the launch follows it) */
 };
 #define VR_LPT_STRIDE_WORDS 64u   /* a tile's length lies in a 256-byte line of its own */
 #define VR_LPT_MAX_TILES 32768u  /* lists of more tiles are neither measured nor ordered */
