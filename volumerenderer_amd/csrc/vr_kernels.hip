@@ -476,8 +476,11 @@ __global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, 
 __global__ __launch_bounds__(kPreThreads) void vr_k_compact(VrViewK v, uint32_t row_begin, uint32_t n_rows, uint32_t center_out,
                                                             const uint32_t *__restrict__ block_off, float4 *__restrict__ ray_dt,
                                                             uint32_t *__restrict__ ray_pix, uint32_t *__restrict__ tile_chord,
-                                                            uint32_t order_max_tiles)
+                                                            uint32_t order_max_tiles, const uint32_t *__restrict__ n_active_ptr)
 {
+    /* a super-tile none of whose rays enters the volume (71 % of the Skull image) has nothing to write: the scan left its
+     * offset equal to its neighbour's */
+    if (block_off[blockIdx.x] == (blockIdx.x + 1u < gridDim.x ? block_off[blockIdx.x + 1u] : *n_active_ptr)) return;
     VrRay ray;
     uint32_t pix, before, total;
     unsigned long long mask;
@@ -2122,7 +2125,7 @@ hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_
                        (uint64_t)n_pix, (uint32_t)((n_pix + 63u) / 64u), tile_cost, tile_order, lpt_max_tiles(grid_lanes),
                        chord_order ? tile_cost - kLptHeaderWords : (uint32_t *)nullptr);
     hipLaunchKernelGGL(vr_k_compact, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt,
-                       pp.ray_dt, pp.ray_pix, chord_order ? tile_cost : (uint32_t *)nullptr, lpt_max_tiles(grid_lanes));
+                       pp.ray_dt, pp.ray_pix, chord_order ? tile_cost : (uint32_t *)nullptr, lpt_max_tiles(grid_lanes), pp.n_active);
     if (chord_order) /* a first call: the order from the chords the kernel above has left */
         hipLaunchKernelGGL(vr_k_tile_order, dim3(1), dim3(1024), 0, stream, (uint32_t)((n_pix + 63u) / 64u), tile_cost, chord_order,
                            lpt_max_tiles(grid_lanes));
