@@ -582,6 +582,10 @@ def test_bench_line_has_the_contract_fields():
         assert key in d["cpu_baseline"], key
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
     assert d["value"] > 100 * d["cpu_baseline"]["value"]
+    # the timed steps repeat one call, so they run with the tiles longest first; what a caller gets who renders a view
+    # once is reported next to it
+    assert d["roofline"]["tiles_longest_first"] is True
+    assert d["first_call"]["ms_per_step"] > 0 and d["first_call"]["kernel_ms"] > 0 and d["first_call"]["value"] > 0
 
 
 SPAN_HEURISTICS = ["MinimizeSpan", "FlexibleFirst5", "FlexibleFirst10", "FlexibleAfter10", "FlexibleAfter15",
