@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 
 #include "vr_internal.h"
 #include "vr_trace_wide.h"
@@ -536,6 +537,18 @@ __device__ unsigned long long g_union_hist[3 * 128]; /* vr_k_union, per 20 us of
 #else
 #define DIAG_T(var)
 #define DIAG_ADD(i, val)
+#endif
+
+#ifdef VR_MEASURE_ITEMS /* measuring build only: the length of every (ray, block of iso values) item of a union launch */
+constexpr uint32_t kMeasureItemsCap = 80u << 20;
+__device__ uint32_t g_item_rounds[kMeasureItemsCap]; /* [ray * n_blocks + block]: rounds from the item's start to the end of its last front */
+__device__ uint32_t g_item_ticks[kMeasureItemsCap];  /* the same in ticks of the 100 MHz clock */
+__device__ uint32_t g_item_begin[kMeasureItemsCap];  /* when the item started, in ticks from the launch's first wave (+ 1) */
+__device__ uint32_t g_item_dims[4];                  /* rays in the list, blocks per ray, iso values per block, first iso value */
+__device__ uint32_t g_trace_slot = 0xffffffffu;      /* the item whose rounds are traced one by one (set by the host from VR_MEASURE_TRACE=ray,block) */
+__device__ uint32_t g_trace_n;
+__device__ unsigned long long g_union_counts[9];     /* see UnionSink::m_count */
+__device__ uint32_t g_trace[2 * 4096];               /* per round of that item: tick since the launch began, lanes of its wave that hold a front | lanes descending << 8 | lanes popping << 16 */
 #endif
 
 #ifndef VR_TRACE_THREADS
@@ -1335,6 +1348,10 @@ struct UnionSink {
     /* iso values that left the front, kept by the lane until an idle lane of the wave takes them or the ray's current
      * front is finished and the lane walks them itself, as a front of their own; three such states of up to four runs each
      * fit, more go to the list */
+#ifdef VR_MEASURE_ITEMS
+    uint32_t m_count[9]; /* trips, low-side parks, of them at the low end of the alive range, high-side parks, of them at the high end, trips
+                          * that parked on both sides, parks of fronts with holes, leaf hits, iso values that hit */
+#endif
     bool pend, pend2, pend3;
     float pend_t, pend2_t, pend3_t;
     uint32_t pend_cell, pend2_cell, pend3_cell;
@@ -1359,6 +1376,9 @@ struct UnionSink {
      * (the MOVE count rides in bits 40-63 of the check sums until the block's prefix sums split them) */
     __device__ __forceinline__ void park(uint32_t r0, uint32_t r1, uint32_t n_checks)
     {
+#ifdef VR_X_NO_PARKS /* experiment: what do the adds of the parked sets cost? (wrong counters) */
+        return;
+#endif
         const unsigned long long both = (unsigned long long)n_checks + (1ull << 40);
         atomicAdd(&s_checks[r0 - iso_begin], both);
         atomicAdd(&s_checks[r1 + 1u - iso_begin], 0ull - both);
@@ -1369,7 +1389,13 @@ struct UnionSink {
         add(0u, r0, r1, 1u);
         const uint8_t g = vr_shade(t); /* shade and store (src/raytrace.zig:56-61), one frame per iso value */
         uint8_t *p = rgb + (uint64_t)(r0 - iso_begin) * frame_bytes + (uint64_t)pix * 3u;
+#ifdef VR_X_NO_STORES /* experiment: what do the pixel stores cost? (wrong frames) */
+        if (frame_bytes == 1u) p[0] = g;
+#elif defined(VR_X_ONE_STORE) /* experiment: one store per run instead of one pixel per iso value (wrong frames) */
+        p[0] = g;
+#else
         for (uint32_t k = r0; k <= r1; k++, p += frame_bytes) { p[0] = g; p[1] = g; p[2] = g; }
+#endif
     }
     __device__ __forceinline__ void miss(uint32_t r0, uint32_t r1) { add(1u, r0, r1, 1u); }
     __device__ __forceinline__ void esc(uint32_t r0, uint32_t r1, uint32_t n) { add(3u, r0, r1, n); }
@@ -1519,6 +1545,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     sink.s_checks = s_checks; sink.s_cnt = s_cnt; sink.n_k = n_k; sink.iso_begin = iso_begin;
     sink.rgb = rgb; sink.frame_bytes = frame_pixels * 3u; sink.pix = 0; sink.ray = 0;
     sink.except_count = (uint32_t *)n_active_ptr + 32; sink.except_list = except_list; sink.except_cap = except_cap;
+#ifdef VR_MEASURE_ITEMS
+    for (int i = 0; i < 9; i++) sink.m_count[i] = 0u;
+#endif
     sink.pend = false; sink.pend_t = 0.0f; sink.pend_cell = 0; sink.pend_runs.clear();
     sink.pend2 = false; sink.pend2_t = 0.0f; sink.pend2_cell = 0; sink.pend2_runs.clear();
     sink.pend3 = false; sink.pend3_t = 0.0f; sink.pend3_cell = 0; sink.pend3_runs.clear();
@@ -1530,6 +1559,14 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     /* lengths are kept only for lists the pre-pass would order (one atomic per item adds up on long lists) */
     uint32_t *const length_out = tile_cost && keep_lengths && ((n_active + 63u) >> 6) <= lpt_max_tiles(gridDim.x * kTraceThreads) ? tile_cost : nullptr;
     uint32_t n_rounds = 0; /* rounds this lane has spent on its item: the item's length, kept per tile for the next launch's order */
+#ifdef VR_MEASURE_ITEMS
+    uint32_t m_slot = 0, m_t0 = 0, m_rounds = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_item_dims[0] = n_active; g_item_dims[1] = n_blocks; g_item_dims[2] = block_isos; g_item_dims[3] = iso_begin; }
+#define VR_MEASURE_ITEM_END() do { if (m_slot < kMeasureItemsCap) { atomicMax(&g_item_rounds[m_slot], m_rounds); \
+        atomicMax(&g_item_ticks[m_slot], (uint32_t)__builtin_amdgcn_s_memrealtime() - m_t0); } } while (0)
+#else
+#define VR_MEASURE_ITEM_END() do { } while (0)
+#endif
 #ifdef VR_DIAG
     uint32_t d_round = 0;
     unsigned long long d_n = 0, d_c1 = 0, d_c2 = 0, d_c3 = 0, d_c4 = 0, d_l1 = 0, d_l2 = 0, d_l3 = 0, d_l4 = 0;
@@ -1562,6 +1599,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
         } else {                                                                                            \
             alive = false;                                                                                  \
             if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], VR_ITEM_LENGTH(n_rounds)); \
+            VR_MEASURE_ITEM_END();                                                                          \
         }                                                                                                   \
     } while (0)
 
@@ -1592,6 +1630,10 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             sink.ray = s_ray;
             UOPS::begin(U, stack, done, v, ray_dt[s_ray], s_iso, s_n);
             alive = true; popping = false; n_states = 0; n_rounds = VR_ITEM_BEGIN();
+#ifdef VR_MEASURE_ITEMS
+            m_slot = s_ray * n_blocks + (s_iso - iso_begin) / block_isos; m_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime(); m_rounds = 0;
+            if (m_slot < kMeasureItemsCap) g_item_begin[m_slot] = m_t0 - (uint32_t)tick_begin + 1u;
+#endif
         }
         if (__ballot(alive) == 0ull) {
             if (exhausted) break;
@@ -1615,6 +1657,20 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
 #endif
         if (alive) {
             n_rounds = VR_ITEM_ROUND(n_rounds);
+#ifdef VR_MEASURE_ITEMS
+            m_rounds++;
+#endif
+        }
+#ifdef VR_MEASURE_ITEMS
+        {
+            const uint32_t t_alive = (uint32_t)__popcll(__ballot(alive)), t_desc = (uint32_t)__popcll(__ballot(alive && !popping));
+            if (alive && m_slot == g_trace_slot) {
+                const uint32_t at = atomicAdd(&g_trace_n, 1u);
+                if (at < 4096u) { g_trace[2u * at] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tick_begin); g_trace[2u * at + 1u] = t_alive | (t_desc << 8) | ((uint32_t)popping << 16) | (m_rounds << 20); }
+            }
+        }
+#endif
+        if (alive) {
             uint32_t go = VR_GO_MORE;
             if (!popping) go = UOPS::descend(U, fetch, stack, done, sink);
 #ifdef VR_DIAG
@@ -1632,6 +1688,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                         sink.pend = false; sink.pend2 = false; sink.pend3 = false;
                         alive = false;
                         if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], VR_ITEM_LENGTH(n_rounds));
+                        VR_MEASURE_ITEM_END();
                     } else if (!x.in_root) {
                         /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
                         const float t_new = U.L.t;
@@ -1698,6 +1755,11 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             g_runs.w23 = (uint32_t)__builtin_amdgcn_readlane((int)sink.pend_runs.w23, giver);
             const uint32_t g_pix = (uint32_t)__builtin_amdgcn_readlane((int)sink.pix, giver);
             const uint32_t g_ray = (uint32_t)__builtin_amdgcn_readlane((int)sink.ray, giver);
+#ifdef VR_MEASURE_ITEMS /* the run goes on as a part of the giver's item: its chain of rounds is the giver's so far plus the taker's */
+            const uint32_t g_slot = (uint32_t)__builtin_amdgcn_readlane((int)m_slot, giver), g_t0 = (uint32_t)__builtin_amdgcn_readlane((int)m_t0, giver);
+            const uint32_t g_rounds = (uint32_t)__builtin_amdgcn_readlane((int)m_rounds, giver);
+            if (lane == taker) { m_slot = g_slot; m_t0 = g_t0; m_rounds = g_rounds; }
+#endif
             UOPS::Ray::adopt(U.L, giver, lane == taker);
             if (lane == giver) sink.pend_shift();
             if (lane == taker) {
@@ -1716,6 +1778,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     }
 #endif
 
+#ifdef VR_MEASURE_ITEMS
+    for (int i = 0; i < 9; i++) { const uint32_t c = wave_sum(sink.m_count[i]); if (lane == 0) atomicAdd(&g_union_counts[i], (unsigned long long)c); }
+#endif
     {
         const uint32_t w_walks = wave_sum(n_walks);
         if (lane == 0) {
@@ -1756,6 +1821,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
 }
 
 #undef VR_FRONT_DONE
+#undef VR_MEASURE_ITEM_END
 #undef VR_ITEM_LENGTH
 #undef VR_ITEM_BEGIN
 #undef VR_ITEM_ROUND
@@ -2351,10 +2417,60 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                    : sweep ? (any_tap ? (const void *)vr_k_sweep<true, SweepNarrow> : (const void *)vr_k_sweep<false, SweepNarrow>)
                            : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
 
+#ifdef VR_MEASURE_ITEMS
+    if (use_union) {
+        void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+        (void)hipGetSymbolAddress(&p0, HIP_SYMBOL(g_item_rounds)); (void)hipGetSymbolAddress(&p1, HIP_SYMBOL(g_item_ticks));
+        (void)hipGetSymbolAddress(&p2, HIP_SYMBOL(g_item_begin));
+        (void)hipMemsetAsync(p0, 0, sizeof(uint32_t) * kMeasureItemsCap, stream); (void)hipMemsetAsync(p1, 0, sizeof(uint32_t) * kMeasureItemsCap, stream);
+        (void)hipMemsetAsync(p2, 0, sizeof(uint32_t) * kMeasureItemsCap, stream);
+        if (getenv("VR_MEASURE_TRACE")) { /* VR_MEASURE_TRACE=ray,block,blocks per ray */
+            unsigned ray = 0, blk = 0, nb = 1;
+            if (sscanf(getenv("VR_MEASURE_TRACE"), "%u,%u,%u", &ray, &blk, &nb) == 3) {
+                const uint32_t slot = ray * nb + blk, zero = 0;
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_slot), &slot, 4); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, 4);
+            }
+        }
+    }
+#endif
     if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
     if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, trace_lds, stream)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+#ifdef VR_MEASURE_ITEMS
+    if (use_union && getenv("VR_MEASURE_DUMP")) { /* [dims: rays, blocks per ray, iso values per block, first iso][rounds][ticks][begin][pixel of every ray] as u32 */
+        (void)hipStreamSynchronize(stream);
+        uint32_t dims[4] = { 0, 0, 0, 0 };
+        (void)hipMemcpyFromSymbol(dims, HIP_SYMBOL(g_item_dims), sizeof dims);
+        const size_t n = (size_t)dims[0] * dims[1] < kMeasureItemsCap ? (size_t)dims[0] * dims[1] : kMeasureItemsCap;
+        std::vector<uint32_t> buf(n);
+        if (FILE *f = fopen(getenv("VR_MEASURE_DUMP"), "wb")) {
+            fwrite(dims, sizeof dims, 1, f);
+            (void)hipMemcpyFromSymbol(buf.data(), HIP_SYMBOL(g_item_rounds), n * sizeof(uint32_t)); fwrite(buf.data(), sizeof(uint32_t), n, f);
+            (void)hipMemcpyFromSymbol(buf.data(), HIP_SYMBOL(g_item_ticks), n * sizeof(uint32_t)); fwrite(buf.data(), sizeof(uint32_t), n, f);
+            (void)hipMemcpyFromSymbol(buf.data(), HIP_SYMBOL(g_item_begin), n * sizeof(uint32_t)); fwrite(buf.data(), sizeof(uint32_t), n, f);
+            buf.resize(dims[0]);
+            (void)hipMemcpy(buf.data(), ray_pix, (size_t)dims[0] * sizeof(uint32_t), hipMemcpyDeviceToHost); fwrite(buf.data(), sizeof(uint32_t), dims[0], f);
+            fclose(f);
+        }
+        {
+            unsigned long long c[9], z[9] = { 0 };
+            (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_union_counts), sizeof c); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_union_counts), z, sizeof z);
+            fprintf(stderr, "[union counts, all launches since the last dump] trips %llu, low-side parks %llu (at the low end of the alive range %llu), high-side parks %llu (at the high end %llu), "
+                    "trips parking on both sides %llu, parks with holes %llu, leaf hits %llu for %llu iso values\n", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]);
+        }
+        if (getenv("VR_MEASURE_TRACE") && getenv("VR_MEASURE_TRACE_OUT")) {
+            uint32_t n = 0; static uint32_t tr[2 * 4096];
+            (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), 4); (void)hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof tr);
+            if (FILE *f = fopen(getenv("VR_MEASURE_TRACE_OUT"), "w")) {
+                for (uint32_t i = 0; i < n && i < 4096u; i++)
+                    fprintf(f, "%u %.2f %u %u %u\n", tr[2 * i + 1] >> 20, tr[2 * i] / 100.0, tr[2 * i + 1] & 255u, (tr[2 * i + 1] >> 8) & 255u, (tr[2 * i + 1] >> 16) & 1u);
+                fclose(f);
+            }
+        }
+    }
+#endif
     if (use_union) { /* the few iso values whose own MOVE parted from the front's */
         const uint32_t fix_top = n_top < (1u << 13) ? n_top : (1u << 13); /* 32 KiB of top levels beside the wave's stack */
         hipLaunchKernelGGL(vr_k_union_fix, dim3(2048), dim3(64), ((size_t)stack_rows * 64u + fix_top) * sizeof(uint32_t), stream, view,

@@ -205,15 +205,29 @@ VR_HD uint32_t vr_union_descend(VrUnionLane &U, const Fetch &fetch, Stack &stack
         const uint32_t n = fetch(L.g);
         const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
         const uint32_t checks = stack.depth() + 1u; /* root .. this node (src/raytrace.zig:162) */
+#ifdef VR_MEASURE_ITEMS
+        uint32_t m_sides = 0;
+        sink.m_count[0]++;
+#endif
         /* present: the parent's range; excluded here: what this node's range leaves out on either side */
         if (mn > U.prev_mn) {
             const uint32_t p = U.prev_mn > U.alive_lo ? U.prev_mn : U.alive_lo, q = mn - 1u < U.alive_hi ? mn - 1u : U.alive_hi;
             if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes);
+#ifdef VR_MEASURE_ITEMS
+            if (p <= q) { m_sides++; sink.m_count[1]++; sink.m_count[2] += p == U.alive_lo ? 1u : 0u; sink.m_count[6] += U.holes ? 1u : 0u; }
+#endif
         }
         if (mx < U.prev_mx) {
             const uint32_t p = mx + 1u > U.alive_lo ? mx + 1u : U.alive_lo, q = U.prev_mx < U.alive_hi ? U.prev_mx : U.alive_hi;
             if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes);
+#ifdef VR_MEASURE_ITEMS
+            if (p <= q) { m_sides++; sink.m_count[3]++; sink.m_count[4] += q == U.alive_hi ? 1u : 0u; sink.m_count[6] += U.holes ? 1u : 0u; }
+#endif
         }
+#ifdef VR_MEASURE_ITEMS
+        sink.m_count[5] += m_sides == 2u ? 1u : 0u;
+        if ((n & VR_N_LEAF) && vr_union_any(done, U, mn, mx)) { sink.m_count[7]++; sink.m_count[8] += (mx < U.alive_hi ? mx : U.alive_hi) - (mn > U.alive_lo ? mn : U.alive_lo) + 1u; }
+#endif
         if (!vr_union_any(done, U, mn, mx)) return VR_GO_EXCLUDED;
         if (n & VR_N_LEAF) {
             const uint32_t p = mn > U.alive_lo ? mn : U.alive_lo, q = mx < U.alive_hi ? mx : U.alive_hi;
