@@ -30,6 +30,11 @@
 #include <mutex>
 #include <vector>
 
+#ifdef VR_MEASURE_ITEMS /* measuring build: how often a wave runs through each piece of the union kernel's lane code */
+__device__ unsigned long long g_wave_counts[24];
+#define VR_WC(i) do { const unsigned long long e__ = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)e__) - 1u) atomicAdd(&g_wave_counts[i], 1ull); } while (0)
+#endif
+
 #include "vr_internal.h"
 #include "vr_trace_wide.h"
 #include "vr_trace_union.h"
@@ -547,7 +552,6 @@ __device__ uint32_t g_item_begin[kMeasureItemsCap];  /* when the item started, i
 __device__ uint32_t g_item_dims[4];                  /* rays in the list, blocks per ray, iso values per block, first iso value */
 __device__ uint32_t g_trace_slot = 0xffffffffu;      /* the item whose rounds are traced one by one (set by the host from VR_MEASURE_TRACE=ray,block) */
 __device__ uint32_t g_trace_n;
-__device__ unsigned long long g_union_counts[9];     /* see UnionSink::m_count */
 __device__ uint32_t g_trace[2 * 4096];               /* per round of that item: tick since the launch began, lanes of its wave that hold a front | lanes descending << 8 | lanes popping << 16 */
 #endif
 
@@ -1348,10 +1352,6 @@ struct UnionSink {
     /* iso values that left the front, kept by the lane until an idle lane of the wave takes them or the ray's current
      * front is finished and the lane walks them itself, as a front of their own; three such states of up to four runs each
      * fit, more go to the list */
-#ifdef VR_MEASURE_ITEMS
-    uint32_t m_count[9]; /* trips, low-side parks, of them at the low end of the alive range, high-side parks, of them at the high end, trips
-                          * that parked on both sides, parks of fronts with holes, leaf hits, iso values that hit */
-#endif
     bool pend, pend2, pend3;
     float pend_t, pend2_t, pend3_t;
     uint32_t pend_cell, pend2_cell, pend3_cell;
@@ -1380,8 +1380,20 @@ struct UnionSink {
         return;
 #endif
         const unsigned long long both = (unsigned long long)n_checks + (1ull << 40);
+#if defined(VR_X_PARK_U32)      /* experiments on what the parked sets' adds cost (wrong counters) */
+        atomicAdd((uint32_t *)&s_checks[r0 - iso_begin], n_checks);
+        atomicAdd((uint32_t *)&s_checks[r1 + 1u - iso_begin], 0u - n_checks);
+#elif defined(VR_X_PARK_FIRST)
+        atomicAdd(&s_checks[r0 - iso_begin], both);
+#elif defined(VR_X_PARK_SECOND)
+        atomicAdd(&s_checks[r1 + 1u - iso_begin], 0ull - both);
+#elif defined(VR_X_PARK_WRITE)
+        s_checks[r0 - iso_begin] = both;
+        s_checks[r1 + 1u - iso_begin] = 0ull - both;
+#else
         atomicAdd(&s_checks[r0 - iso_begin], both);
         atomicAdd(&s_checks[r1 + 1u - iso_begin], 0ull - both);
+#endif
     }
     __device__ __forceinline__ void hit(uint32_t r0, uint32_t r1, uint32_t n_checks, float t, uint32_t, uint32_t)
     {
@@ -1394,7 +1406,8 @@ struct UnionSink {
 #elif defined(VR_X_ONE_STORE) /* experiment: one store per run instead of one pixel per iso value (wrong frames) */
         p[0] = g;
 #else
-        for (uint32_t k = r0; k <= r1; k++, p += frame_bytes) { p[0] = g; p[1] = g; p[2] = g; }
+        VR_WC(16);
+        for (uint32_t k = r0; k <= r1; k++, p += frame_bytes) { VR_WC(6); p[0] = g; p[1] = g; p[2] = g; }
 #endif
     }
     __device__ __forceinline__ void miss(uint32_t r0, uint32_t r1) { add(1u, r0, r1, 1u); }
@@ -1545,9 +1558,6 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     sink.s_checks = s_checks; sink.s_cnt = s_cnt; sink.n_k = n_k; sink.iso_begin = iso_begin;
     sink.rgb = rgb; sink.frame_bytes = frame_pixels * 3u; sink.pix = 0; sink.ray = 0;
     sink.except_count = (uint32_t *)n_active_ptr + 32; sink.except_list = except_list; sink.except_cap = except_cap;
-#ifdef VR_MEASURE_ITEMS
-    for (int i = 0; i < 9; i++) sink.m_count[i] = 0u;
-#endif
     sink.pend = false; sink.pend_t = 0.0f; sink.pend_cell = 0; sink.pend_runs.clear();
     sink.pend2 = false; sink.pend2_t = 0.0f; sink.pend2_cell = 0; sink.pend2_runs.clear();
     sink.pend3 = false; sink.pend3_t = 0.0f; sink.pend3_cell = 0; sink.pend3_runs.clear();
@@ -1592,6 +1602,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
 #define VR_FRONT_DONE()                                                                                     \
     do {                                                                                                    \
         if (sink.pend) {                                                                                    \
+            VR_WC(12);                                                                                      \
             UOPS::restart(U, stack, done, v, sink.pend_t, sink.pend_cell, sink.pend_runs);                  \
             sink.pend_shift();                                                                              \
             popping = false;                                                                                \
@@ -1609,7 +1620,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         bool start = false;            /* this lane begins a front: on ray s_ray, for s_n iso values from s_iso on */
         uint32_t s_ray = 0, s_iso = 1u, s_n = 0;
+        VR_WC(15);
         if (!exhausted && n_idle >= kUnionRefillMin) {
+            VR_WC(13);
             uint32_t mine;
             const bool got = chunk.take(n_idle, (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), head, n_items, n_idle, lane, mine);
             if (!alive && got) {
@@ -1626,6 +1639,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             if (exhausted && !tick_empty) tick_empty = __builtin_amdgcn_s_memrealtime();
         }
         if (start) {
+            VR_WC(17);
             sink.pix = ray_pix[s_ray];
             sink.ray = s_ray;
             UOPS::begin(U, stack, done, v, ray_dt[s_ray], s_iso, s_n);
@@ -1677,6 +1691,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             d_t1 = __builtin_amdgcn_s_memtime();
 #endif
             if (go == VR_GO_EXCLUDED) {
+                VR_WC(19);
                 if (U.alive_lo > U.alive_hi) {
                     VR_FRONT_DONE(); /* every iso value of the front has hit */
                 } else {
@@ -1713,6 +1728,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             d_t2 = __builtin_amdgcn_s_memtime();
 #endif
             if (popping && alive) {
+                VR_WC(18);
                 VrUnionFrom from = UOPS::root(v);
                 if (UOPS::pop(U, stack, x, suspect, from)) {
                     popping = false;
@@ -1746,6 +1762,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
         for (;;) {
             const unsigned long long givers = __ballot(alive && sink.pend), takers = __ballot(!alive);
             if (givers == 0ull || takers == 0ull) break;
+            VR_WC(14);
             const uint32_t giver = (uint32_t)__ffsll((long long)givers) - 1u, taker = (uint32_t)__ffsll((long long)takers) - 1u;
             const float g_t = lane_f(sink.pend_t, giver);
             const uint32_t g_cell = (uint32_t)__builtin_amdgcn_readlane((int)sink.pend_cell, giver);
@@ -1778,9 +1795,6 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     }
 #endif
 
-#ifdef VR_MEASURE_ITEMS
-    for (int i = 0; i < 9; i++) { const uint32_t c = wave_sum(sink.m_count[i]); if (lane == 0) atomicAdd(&g_union_counts[i], (unsigned long long)c); }
-#endif
     {
         const uint32_t w_walks = wave_sum(n_walks);
         if (lane == 0) {
@@ -2455,10 +2469,13 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
             fclose(f);
         }
         {
-            unsigned long long c[9], z[9] = { 0 };
-            (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_union_counts), sizeof c); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_union_counts), z, sizeof z);
-            fprintf(stderr, "[union counts, all launches since the last dump] trips %llu, low-side parks %llu (at the low end of the alive range %llu), high-side parks %llu (at the high end %llu), "
-                    "trips parking on both sides %llu, parks with holes %llu, leaf hits %llu for %llu iso values\n", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]);
+            unsigned long long c[24], z[24] = { 0 };
+            (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_wave_counts), sizeof c); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_counts), z, sizeof z);
+            static const char *what[24] = { "descend trips", "low-side parks", "high-side parks", "iterations of the run loop (done bits)", "done words read by the does-anybody-hold test",
+                "leaves", "iterations of the pixel-store loop", "MOVEs", "iterations of the escape loop", "levels left on the way out of the volume", "levels of exact resolutions",
+                "pop trips", "fronts restarted from kept runs", "refills", "hand-overs", "rounds", "hit runs", "items begun", "pop phases", "ends of a descent" };
+            fprintf(stderr, "[wave counts: how often a wave ran through a piece of the lane code, all launches since the last dump]\n");
+            for (int i = 0; i < 20; i++) fprintf(stderr, "  %-50s %12llu  (%.2f per round)\n", what[i], c[i], c[15] ? (double)c[i] / (double)c[15] : 0.0);
         }
         if (getenv("VR_MEASURE_TRACE") && getenv("VR_MEASURE_TRACE_OUT")) {
             uint32_t n = 0; static uint32_t tr[2 * 4096];

@@ -39,6 +39,12 @@
 /* The lane code of a front is large (runs of iso values, both sides of a range, exact resolution): the level loop is
  * not unrolled, so that the kernel's loop stays inside the instruction cache.  (Nothing is called out of line: a call
  * makes the kernel use scratch memory, and with scratch the whole grid is no longer resident at once.) */
+/* measuring builds count how often a wave runs through a piece of the lane code (VR_WC(i): one count per wave, whatever the
+ * number of its lanes that are there); the product build compiles it to nothing */
+#ifndef VR_WC
+#define VR_WC(i) do { } while (0)
+#endif
+
 #if defined(__clang__)
 #define VR_ROLLED _Pragma("unroll 1")
 #else
@@ -64,6 +70,7 @@ VR_HD void vr_union_runs(const Done &done, uint32_t p, uint32_t q, F f, bool hol
     if (!holes) { f(p, q); return; } /* p, q are clipped to [alive_lo, alive_hi] by every caller */
     uint32_t i = p;
     while (i <= q) {
+        VR_WC(3);
         /* next iso value >= i that is not done */
         uint32_t w = i >> 5;
         uint32_t bits = ~done.word(w) >> (i & 31u);
@@ -104,6 +111,7 @@ VR_HD bool vr_union_any(const Done &done, const ULane &U, uint32_t mn, uint32_t 
     if (!U.holes || (mn <= U.alive_lo && U.alive_lo <= mx) || (mn <= U.alive_hi && U.alive_hi <= mx)) return true;
     /* strictly inside (alive_lo, alive_hi) here: the bits are valid */
     for (uint32_t w = mn >> 5; w <= (mx >> 5); w++) {
+        VR_WC(4);
         const uint32_t a = w == (mn >> 5) ? (mn & 31u) : 0u, b = w == (mx >> 5) ? (mx & 31u) : 31u;
         const uint32_t m = (0xffffffffu >> (31u - b)) & (0xffffffffu << a);
         if (~done.word(w) & m) return true;
@@ -205,31 +213,19 @@ VR_HD uint32_t vr_union_descend(VrUnionLane &U, const Fetch &fetch, Stack &stack
         const uint32_t n = fetch(L.g);
         const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
         const uint32_t checks = stack.depth() + 1u; /* root .. this node (src/raytrace.zig:162) */
-#ifdef VR_MEASURE_ITEMS
-        uint32_t m_sides = 0;
-        sink.m_count[0]++;
-#endif
+        VR_WC(0);
         /* present: the parent's range; excluded here: what this node's range leaves out on either side */
         if (mn > U.prev_mn) {
             const uint32_t p = U.prev_mn > U.alive_lo ? U.prev_mn : U.alive_lo, q = mn - 1u < U.alive_hi ? mn - 1u : U.alive_hi;
-            if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes);
-#ifdef VR_MEASURE_ITEMS
-            if (p <= q) { m_sides++; sink.m_count[1]++; sink.m_count[2] += p == U.alive_lo ? 1u : 0u; sink.m_count[6] += U.holes ? 1u : 0u; }
-#endif
+            if (p <= q) { VR_WC(1); vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes); }
         }
         if (mx < U.prev_mx) {
             const uint32_t p = mx + 1u > U.alive_lo ? mx + 1u : U.alive_lo, q = U.prev_mx < U.alive_hi ? U.prev_mx : U.alive_hi;
-            if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes);
-#ifdef VR_MEASURE_ITEMS
-            if (p <= q) { m_sides++; sink.m_count[3]++; sink.m_count[4] += q == U.alive_hi ? 1u : 0u; sink.m_count[6] += U.holes ? 1u : 0u; }
-#endif
+            if (p <= q) { VR_WC(2); vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes); }
         }
-#ifdef VR_MEASURE_ITEMS
-        sink.m_count[5] += m_sides == 2u ? 1u : 0u;
-        if ((n & VR_N_LEAF) && vr_union_any(done, U, mn, mx)) { sink.m_count[7]++; sink.m_count[8] += (mx < U.alive_hi ? mx : U.alive_hi) - (mn > U.alive_lo ? mn : U.alive_lo) + 1u; }
-#endif
         if (!vr_union_any(done, U, mn, mx)) return VR_GO_EXCLUDED;
         if (n & VR_N_LEAF) {
+            VR_WC(5);
             const uint32_t p = mn > U.alive_lo ? mn : U.alive_lo, q = mx < U.alive_hi ? mx : U.alive_hi;
             vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.hit(r0, r1, checks, L.t, L.cell, L.g); }, U.holes);
             if (!U.holes && (p == U.alive_lo || q == U.alive_hi)) { /* hits off either end leave no hole */
@@ -309,7 +305,9 @@ VR_HD VrUnionExit vr_union_move(VrLane &L, const VrViewK &v)
     t += 0.0001f;
     float i = 0.0f;
     x.esc = 0u;
+    VR_WC(7);
     for (;;) {
+        VR_WC(8);
         const float px = v.ox + L.dx * t, py = v.oy + L.dy * t, pz = v.oz + L.dz * t;
         const uint32_t cx = (uint32_t)vr_floor_i32(px), cy = (uint32_t)vr_floor_i32(py), cz = (uint32_t)vr_floor_i32(pz);
         x.in_root = (cx < v.rdx) & (cy < v.rdy) & (cz < v.rdz);
@@ -335,6 +333,7 @@ VR_HD bool vr_union_pop(VrLane &L, Stack &stack, uint32_t max_trips, const VrUni
     uint32_t word = 0, a_lo = 0, a_hi = 0;
     bool left = false, found = false;
     for (uint32_t trip = 0; trip < max_trips; trip++) {
+        VR_WC(11);
         word = next;
         stack.up();
         next = stack.peek_up(1);
@@ -368,6 +367,7 @@ template <class Stack>
 VR_HD void vr_union_leave(VrLane &L, Stack &stack, const VrUnionExit &x, bool &suspect)
 {
     while (stack.depth() > 0u) {
+        VR_WC(9);
         const uint32_t word = stack.peek_up(1); /* the top entry: the bound the last split replaced */
         stack.up();
         const bool left = (L.g & 1u) == 0u;
@@ -395,6 +395,7 @@ VR_HD void vr_union_resolve(VrUnionLane &U, const VrViewK &v, const Fetch &fetch
     uint32_t g = from.node, lo = from.lo, hi = from.hi, prev_mn = 0u, prev_mx = 255u;
     bool marked = false;
     for (uint32_t m = a_level < 0 ? 0u : (uint32_t)a_level; m <= depth_k; m++) {
+        VR_WC(10);
         const uint32_t n = fetch(g);
         const uint32_t mn = n & 0xffu, mx = (n >> 8) & 0xffu;
         if ((int)m > a_level) {
