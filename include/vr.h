@@ -372,6 +372,11 @@ typedef struct vr_sweep_info {
     uint32_t list_runs;      /* union kernel: runs of iso values that its second kernel had to finish (normally 0) */
     uint32_t tiles_longest_first; /* union kernel: 1 when the launch repeated the context's previous call and started its tiles of
                                    * 64 rays in the order of the item lengths that call left (longest first), 0 = list order */
+    uint32_t rendered_again; /* union kernel: 1 when it could not finish the call exactly (more than 32 768 runs of iso values left
+                              * its walks, or one front passed 2^20 MOVEs) and the call was rendered again, on the same stream and
+                              * before anything the caller enqueued behind it, by the kernel that shares traversals between iso
+                              * values; frames and counters are the same either way */
+    uint32_t reserved;
 } vr_sweep_info;
 int vr_sweep_info_read(vr_ctx *ctx, vr_sweep_info *out);
 

@@ -143,3 +143,13 @@ def random_volume(rng, shape, kind):
         v[m] = rng.integers(1, 256, size=int(m.sum()), dtype=np.uint8)
         return v
     raise ValueError(kind)
+
+
+def fullsize_golden_stats(name):
+    """The oracle's seven counters per frame of one of the full-size fixtures (tests/golden/fullsize_oracle.json, written by
+    tests/golden/make_fullsize_golden.py): int64 [frames, 7] in the order of vr_render_stats."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_oracle.json")) as f:
+        gold = json.load(f)[name]
+    return np.array([fr["stats"] for fr in gold["frames"]], dtype=np.int64)

@@ -7,6 +7,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import helpers
+
 import volumerenderer_amd as vr
 from volumerenderer_amd import capi
 from test_gpu_parity import c60_renderer, skull_renderer, standin_tree, standin_renderer, _check_stats  # noqa: F401
@@ -55,7 +57,8 @@ def test_union_kernel_equals_per_iso_kernel_at_full_size(oracle, skull_vox, skul
     for k in (1, 2):
         assert (res[0][1] == res[k][1]).all(), np.argwhere(res[0][1] != res[k][1])[:8]
         assert bool(torch.equal(res[0][0], res[k][0]))
-    assert int(res[0][1][:, 0].sum()) == 8519971365 and int(res[0][1][:, 6].sum()) == 0
+    # every frame's counters are the oracle's (tests/golden/fullsize_oracle.json, made by the CPU oracle)
+    assert (res[0][1] == helpers.fullsize_golden_stats("skull_1024")).all() and int(res[0][1][:, 6].sum()) == 0
     si = capi.SweepInfo()
     capi.check(L.vr_sweep_info_read(skull_renderer.handle, C.byref(si)), "vr_sweep_info_read")
     assert si.walks == si.items and si.walks >= 250000  # one traversal per entering ray and block of iso values
@@ -159,3 +162,54 @@ def test_union_kernel_with_no_ray_entering_the_volume_and_with_taps(oracle, c60_
         ref = oracle.render(nodes, rd, pos, forw, up, 40, 40, 2.0, 90 + j)
         assert (out["rgb"][j] == ref["rgb"]).all() and (out["checked"][j] == ref["checked"]).all()
         assert (out["t"][j].view(np.uint32) == ref["t"].view(np.uint32)).all()
+
+
+def test_union_kernel_that_gives_up_renders_the_call_again(oracle, monkeypatch):
+    """When more runs of iso values leave the union walks of a call than its list holds, or a front passes the bound on its
+    MOVEs, the union kernel sets a word in the call's scratch; its second kernel then clears the frames and counters instead of
+    finishing the list, and the kernel that shares traversals between iso values, enqueued behind every union launch, renders
+    the call again before the caller sees anything.  No volume tried so far fills the list (a lane keeps three states of runs
+    that left its front), so the word is set from the host (VR_UNION_FORCE_REDO): frames and all 7 counters equal the per-iso
+    kernel's and the oracle's, the report says that the call was rendered again, and the calls after it are normal ones.
+    Narrow and wide trees, whole frames and a row range."""
+    import torch
+    from helpers import random_volume
+    L = capi.lib()
+    rng = np.random.default_rng(31)
+    for shape, wide, W, H, r0, r1 in [((48, 40, 44), False, 256, 192, 0, 192), ((300, 24, 20), True, 160, 128, 17, 100)]:
+        vox = random_volume(rng, shape, "noise")
+        nodes, rd, _ = oracle.build_kdt(vox, wide=wide)
+        pos, forw, up = oracle.main_camera(vox.shape)
+        v = vr.raytrace._view(pos, forw, up, W, H, 2.5)
+        with vr.Renderer(0) as r:
+            r.upload_kdt(vr.SlimKDT(nodes, rd, wide=wide))
+
+            def run(variant):
+                r.set_kernel(variant)
+                d_rgb = torch.full((256, r1 - r0, W, 3), 7, dtype=torch.uint8, device="cuda")
+                d_stats = torch.full((256, 7), 5, dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()  # the fills run on torch's stream, the render on the context's own
+                capi.check(L.vr_render_device(r.handle, C.byref(v), 0, 256, r0, r1, d_rgb.data_ptr(), d_stats.data_ptr(), None, None),
+                           "vr_render_device")
+                capi.check(L.vr_sync(r.handle), "vr_sync")
+                si = capi.SweepInfo()
+                if variant != capi.KERNEL_PIPELINE:
+                    capi.check(L.vr_sweep_info_read(r.handle, C.byref(si)), "vr_sweep_info_read")
+                return d_rgb, d_stats.cpu().numpy(), si
+
+            ref = run(capi.KERNEL_PIPELINE)
+            usual = run(capi.KERNEL_UNION)
+            monkeypatch.setenv("VR_UNION_FORCE_REDO", "1")
+            forced = run(capi.KERNEL_UNION)
+            again = run(capi.KERNEL_DEFAULT)  # and the call after a call that was rendered again
+            monkeypatch.delenv("VR_UNION_FORCE_REDO")
+            after = run(capi.KERNEL_UNION)
+            assert usual[2].rendered_again == 0 and forced[2].rendered_again == 1 and again[2].rendered_again == 1 and after[2].rendered_again == 0
+            for got in (usual, forced, again, after):
+                assert (got[1] == ref[1]).all(), (shape, np.argwhere(got[1] != ref[1])[:8])
+                assert bool(torch.equal(got[0], ref[0])), shape
+            assert int(ref[1][:, 6].sum()) == 0 and int(ref[1][:, 1].sum()) > 1000
+        for iso in (3, 120, 250):
+            o = oracle.render(nodes, rd, pos, forw, up, W, H, 2.5, iso, rows=(r0, r1), wide=wide)
+            assert (forced[0][iso].cpu().numpy() == o["rgb"][r0:r1]).all(), (shape, iso)
+            assert int(forced[1][iso, 0]) == o["stats"].nodes_checked and int(forced[1][iso, 5]) == o["stats"].moves

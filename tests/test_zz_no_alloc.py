@@ -14,8 +14,10 @@ from volumerenderer_amd import capi
 pytestmark = pytest.mark.gpu
 
 
-def _both(r, pos, forw, up, W, H, b, n, r0, r1):
-    """Renders rows [r0, r1) of n frames with both entry points; returns their outputs as numpy arrays."""
+def _both(r, pos, forw, up, W, H, b, n, r0, r1, with_taps=True):
+    """Renders rows [r0, r1) of n frames with both entry points; returns their outputs as numpy arrays.  Without taps a
+    call of 8 or more iso values runs the kernel with one traversal per ray for the whole iso range, whose list of iso
+    runs and counters lie in the scratch as well."""
     import torch
     L = capi.lib()
     v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
@@ -24,10 +26,10 @@ def _both(r, pos, forw, up, W, H, b, n, r0, r1):
         rows = r1 - r0
         d_rgb = torch.full((n, rows, W, 3), 9, dtype=torch.uint8, device="cuda")
         d_stats = torch.full((n, 7), -1, dtype=torch.int64, device="cuda")
-        d_tap = [torch.full((n, rows, W), 5, dtype=torch.int32, device="cuda") for _ in range(4)]
-        taps = capi.Taps(*[t.data_ptr() for t in d_tap])
+        d_tap = [torch.full((n, rows, W), 5, dtype=torch.int32, device="cuda") for _ in range(4 if with_taps else 0)]
+        taps = capi.Taps(*[t.data_ptr() for t in d_tap]) if with_taps else None
         torch.cuda.synchronize()
-        capi.check(fn(r.handle, C.byref(v), b, n, r0, r1, d_rgb.data_ptr(), d_stats.data_ptr(), C.byref(taps), None), name)
+        capi.check(fn(r.handle, C.byref(v), b, n, r0, r1, d_rgb.data_ptr(), d_stats.data_ptr(), C.byref(taps) if with_taps else None, None), name)
         capi.check(L.vr_sync(r.handle), "vr_sync")
         res.append([d_rgb.cpu().numpy(), d_stats.cpu().numpy()] + [t.cpu().numpy() for t in d_tap])
     return res
@@ -35,9 +37,38 @@ def _both(r, pos, forw, up, W, H, b, n, r0, r1):
 
 def _assert_equal(res, what):
     a, b = res
-    for i, name in enumerate(("rgb", "stats", "cell_flag", "t", "checked", "node")):
+    for i, name in enumerate(("rgb", "stats", "cell_flag", "t", "checked", "node")[:len(a)]):
         assert (a[i] == b[i]).all(), "%s: %s differs" % (what, name)
     assert a[1][:, 1].sum() > 0 and (a[1][:, 6] == 0).all(), what  # something was hit, no errors
+
+
+def test_noalloc_entry_point_without_taps_runs_the_union_kernel(oracle, c60_vox, c60_tree, skull_vox, skull_tree):
+    """The normal serving call -- no taps, 8 or more iso values -- goes to the kernel with one traversal per ray, its second
+    kernel and its list in the static array: frames and all 7 counters equal vr_render_device's, a large call and then a
+    small one, for the default selection and with the sweep / union kernels named; one frame set also against the oracle."""
+    for vox, tree, cases in ((skull_vox, skull_tree, [(512, 512, 40, 64, 0, 512), (200, 160, 70, 12, 31, 140)]),
+                             (c60_vox, c60_tree, [(256, 256, 0, 256, 0, 256), (64, 48, 96, 9, 5, 40)])):
+        nodes, rd, _ = tree
+        pos, forw, up = oracle.main_camera(vox.shape)
+        with vr.Renderer(0) as r:
+            r.upload_kdt(vr.SlimKDT(nodes, rd))
+            for variant in (capi.KERNEL_DEFAULT, capi.KERNEL_UNION, capi.KERNEL_SWEEP):
+                r.set_kernel(variant)
+                for (W, H, b, n, r0, r1) in cases:
+                    res = _both(r, pos, forw, up, W, H, b, n, r0, r1, with_taps=False)
+                    _assert_equal(res, "%s %dx%d x %d iso, kernel %d, no taps" % (vox.shape, W, H, n, variant))
+            W, H, b, n, r0, r1 = cases[1]
+            for j in (0, n - 1):
+                ref = oracle.render(nodes, rd, pos, forw, up, W, H, 2.0, b + j, rows=(r0, r1))
+                assert (res[1][0][j] == ref["rgb"][r0:r1]).all() and res[1][1][j, 0] == ref["stats"].nodes_checked
+    rng = np.random.default_rng(6)
+    vox = (rng.random((300, 20, 24)) * 255).astype(np.uint8)
+    with vr.Renderer(0) as r:  # a wide tree, 8 or more iso values
+        r.upload_volume(vr.Data(vox))
+        r.build_kdt("AlwaysCenter")
+        pos, forw, up = oracle.main_camera(vox.shape)
+        _assert_equal(_both(r, pos, forw, up, 160, 120, 90, 40, 0, 120, with_taps=False), "wide 160x120 x 40 iso, no taps")
+        _assert_equal(_both(r, pos, forw, up, 64, 48, 100, 8, 8, 40, with_taps=False), "wide 64x48 rows 8..40 x 8 iso, no taps")
 
 
 def test_noalloc_entry_point_equals_vr_render_device(oracle, c60_vox, c60_tree, skull_vox, skull_tree):

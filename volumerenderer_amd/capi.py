@@ -67,7 +67,8 @@ class View(C.Structure):
 class SweepInfo(C.Structure):
     _fields_ = [("walks", C.c_uint64), ("items", C.c_uint64), ("tick_begin", C.c_uint64),
                 ("tick_queue_empty", C.c_uint64), ("tick_end", C.c_uint64), ("items_per_lane", C.c_uint32),
-                ("cut_settled", C.c_uint32), ("list_runs", C.c_uint32), ("tiles_longest_first", C.c_uint32)]
+                ("cut_settled", C.c_uint32), ("list_runs", C.c_uint32), ("tiles_longest_first", C.c_uint32),
+                ("rendered_again", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class RayStep(C.Structure):

@@ -985,7 +985,11 @@ int vr_sweep_info_read(vr_ctx *c, vr_sweep_info *out)
     VR_HIP(hipSetDevice(c->device));
     VR_HIP(hipStreamSynchronize(c->stream));
     VR_HIP(hipMemcpy(out, (const char *)c->d_work + c->info_off, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    VR_HIP(hipMemcpy(&out->list_runs, (const char *)c->d_work + c->info_off + 64, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t runs_redo[2] = { 0u, 0u }; /* the union kernel's count of runs on its list, and its request to render the call again */
+    VR_HIP(hipMemcpy(runs_redo, (const char *)c->d_work + c->info_off + 64, sizeof runs_redo, hipMemcpyDeviceToHost));
+    out->list_runs = runs_redo[0];
+    out->rendered_again = runs_redo[1] ? 1u : 0u;
+    out->reserved = 0u;
     out->tiles_longest_first = 0;
     if (c->order_flag_off) { /* 1 = ordered by item lengths; 2 (a first call's order by chords) is not reported as that */
         uint32_t made_from = 0;

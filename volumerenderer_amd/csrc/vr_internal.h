@@ -40,7 +40,8 @@ enum {
 #define VR_UNION_ITEMS_FIRST 3u
 /* iso values per call from which the default is the kernel with one traversal per ray for all of them */
 #define VR_UNION_MIN_ISOS 8u
-/* runs of iso values that may leave the union walks of one call (a few per thousand rays do) */
+/* runs of iso values that may leave the union walks of one call and be finished one iso value at a time (a few per thousand
+ * rays do); a call that has more is rendered again with the kernel that shares traversals between iso values */
 #define VR_UNION_EXCEPT_CAP 32768u
 
 /* Are the density ranges of a prepared tree nested along every path (vr_host.cpp)? */

@@ -465,6 +465,7 @@ __global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, 
         unsigned long long *info = (unsigned long long *)(n_active_out + 16);
         info[0] = 0; info[1] = 0; info[2] = ~0ull; info[3] = ~0ull; info[4] = 0; info[5] = 0;
         n_active_out[32] = 0u; /* the union kernel's count of iso runs that left the union walk (128 bytes behind the ray count) */
+        n_active_out[33] = 0u; /* ... and its request to render the call again with the sweep kernel (kUnionRedoWord) */
         if (chord_header) chord_header[0] = (total + 63u) >> 6; /* a first call orders its tiles by their rays' chords: the list's tiles */
     }
     /* the small set-up work of a call rides along: empty queues, and the per-iso counters at their starting
@@ -1016,6 +1017,13 @@ struct SweepWide {
     }
 };
 
+/* Words of the 256-byte block behind the ray count (n_active): [16..27] the sweep kernels' report, [32] the union kernel's count of
+ * iso runs that left its walks, [33] set by the union kernel when it could not finish a call exactly -- its list of such runs was
+ * full, or a front passed the bound on its MOVEs: the frames it leaves are then incomplete, vr_k_union_fix clears them and the
+ * counters instead of finishing the list, and a launch of vr_k_sweep that is enqueued behind every union launch (and returns at
+ * once while the word is zero) renders the whole call again. */
+constexpr uint32_t kUnionRedoWord = 33u;
+
 template <bool TAPS, class OPS>
 __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top,
                                                             uint32_t stack_rows,
@@ -1025,8 +1033,10 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                                                             uint32_t *__restrict__ head, uint32_t iso_begin,
                                                             uint32_t iso_count, uint64_t frame_pixels,
                                                             uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
-                                                            VrTapsK taps, uint32_t items_per_lane, uint32_t launch_seq)
+                                                            VrTapsK taps, uint32_t items_per_lane, uint32_t launch_seq,
+                                                            const uint32_t *__restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return; /* the launch behind a union launch: only when that one asked for it */
     /* dynamic LDS: [path stacks][check sums: (iso_count + 1) x u64][counters: 5 x (iso_count + 1) x u32][top node words] */
     extern __shared__ uint32_t s_dyn[];
     unsigned long long *s_checks = (unsigned long long *)(s_dyn + stack_rows * kTraceThreads);
@@ -1325,6 +1335,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
 #endif
 constexpr uint32_t kUnionDescendTrips = VR_UNION_DESCEND_TRIPS, kUnionPopTrips = VR_UNION_POP_TRIPS;
 constexpr uint32_t kUnionRefillMin = VR_UNION_REFILL_MIN;
+constexpr uint32_t kParkMoveShift = 35u; /* see UnionSink::park */
 constexpr uint32_t kUnionMaxStates = 1u << 20; /* MOVEs of one front: the safety valve (VR_MAX_CHECKED in the other kernels) */
 
 struct VrUnionRecord { uint32_t ray, run, t_bits, cell, esc, pad[3]; }; /* run = r0 | r1 << 8 | in_root << 16 */
@@ -1346,7 +1357,7 @@ struct UnionSink {
     uint8_t *rgb;
     uint64_t frame_bytes;
     uint32_t pix, ray;
-    uint32_t *except_count;
+    uint32_t *except_count; /* [0] the count, [1] (kUnionRedoWord): set when the call has to be rendered again */
     VrUnionRecord *except_list;
     uint32_t except_cap;
     /* iso values that left the front, kept by the lane until an idle lane of the wave takes them or the ray's current
@@ -1372,14 +1383,17 @@ struct UnionSink {
         atomicAdd(&s_checks[r0 - iso_begin], (unsigned long long)amount);
         atomicAdd(&s_checks[r1 + 1u - iso_begin], 0ull - (unsigned long long)amount);
     }
-    /* excluded at a node: the checks of this round and the MOVE out of the node's box, in one 64-bit add each way
-     * (the MOVE count rides in bits 40-63 of the check sums until the block's prefix sums split them) */
+    /* excluded at a node: the checks of this round and the MOVE out of the node's box, in one 64-bit add each way (the MOVE
+     * count rides in the bits from kParkMoveShift on of the check sums until the block's prefix sums split them).  A parked set
+     * has checked at most 32 nodes (the deepest level + 1) per MOVE, so 29 bits of MOVEs and 35 bits of checks fill up together:
+     * exact while one block counts fewer than 2^29 such MOVEs for one iso value in one launch, which 8192 x 8192 rays with 2 000
+     * MOVEs each, spread over the 256 blocks of the grid, stay below. */
     __device__ __forceinline__ void park(uint32_t r0, uint32_t r1, uint32_t n_checks)
     {
 #ifdef VR_X_NO_PARKS /* experiment: what do the adds of the parked sets cost? (wrong counters) */
         return;
 #endif
-        const unsigned long long both = (unsigned long long)n_checks + (1ull << 40);
+        const unsigned long long both = (unsigned long long)n_checks + (1ull << kParkMoveShift);
 #if defined(VR_X_PARK_U32)      /* experiments on what the parked sets' adds cost (wrong counters) */
         atomicAdd((uint32_t *)&s_checks[r0 - iso_begin], n_checks);
         atomicAdd((uint32_t *)&s_checks[r1 + 1u - iso_begin], 0u - n_checks);
@@ -1446,7 +1460,7 @@ struct UnionSink {
             return;
         }
         const uint32_t at = atomicAdd(except_count, 1u);
-        if (at >= except_cap) { error(r0, r1); return; } /* never seen: the list holds 65536 runs */
+        if (at >= except_cap) { except_count[1] = 1u; return; } /* the list is full (VR_UNION_EXCEPT_CAP runs): the call is rendered again */
         VrUnionRecord rec;
         rec.ray = ray; rec.run = r0 | (r1 << 8) | ((in_root ? 1u : 0u) << 16);
         rec.t_bits = __builtin_bit_cast(uint32_t, t); rec.cell = cell; rec.esc = n_esc;
@@ -1698,8 +1712,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     depth_k = UOPS::depth(U, stack); cell_before = UOPS::cell(U);
                     x = UOPS::move(U, v);
                     suspect = false; /* set where a box that is left does not share the front's exit plane */
-                    if (++n_states > kUnionMaxStates) { /* safety valve: the iso values left are reported as errors */
-                        vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.error(r0, r1); sink.miss(r0, r1); }, U.holes);
+                    if (++n_states > kUnionMaxStates) { /* safety valve: the front is given up and the call rendered again */
+                        sink.except_count[1] = 1u;
                         sink.pend = false; sink.pend2 = false; sink.pend3 = false;
                         alive = false;
                         if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], VR_ITEM_LENGTH(n_rounds));
@@ -1824,10 +1838,10 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     if (stats) {
         for (uint32_t k = threadIdx.x; k < iso_count; k += kTraceThreads) {
             vr_render_stats *s = stats + k;
-            add_stat(&s->nodes_checked, s_checks[k] & ((1ull << 40) - 1ull));
+            add_stat(&s->nodes_checked, s_checks[k] & ((1ull << kParkMoveShift) - 1ull));
             add_stat(&s->hit_count, s_cnt[k]);
             add_stat(&s->miss_count, s_cnt[n_k + k]);
-            add_stat(&s->moves, (s_checks[k] >> 40) + s_cnt[2u * n_k + k]);
+            add_stat(&s->moves, (s_checks[k] >> kParkMoveShift) + s_cnt[2u * n_k + k]);
             add_stat(&s->escape_help_events, s_cnt[3u * n_k + k]);
             add_stat(&s->errors, s_cnt[4u * n_k + k]);
         }
@@ -1841,14 +1855,38 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
 #undef VR_ITEM_ROUND
 #undef VR_ITEM_PART
 
+/* The union kernel asked for the call to be rendered again (kUnionRedoWord): every block of the fix kernel's grid clears its
+ * share of the frames, and the first one puts the per-iso counters and the queue heads back to where the pre-pass left them. */
+__device__ void union_redo_clear(const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ heads, uint32_t iso_count,
+                                 uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats)
+{
+    const uint64_t bytes = frame_pixels * 3u * iso_count;
+    const uint64_t head = (16u - ((uintptr_t)rgb & 15u)) & 15u, lead = head < bytes ? head : bytes;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_threads = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = tid; i < lead; i += n_threads) rgb[i] = 0u;
+    const uint64_t n16 = (bytes - lead) / 16u;
+    uint4 *mid = (uint4 *)(rgb + lead);
+    for (uint64_t i = tid; i < n16; i += n_threads) mid[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint64_t i = lead + n16 * 16u + tid; i < bytes; i += n_threads) rgb[i] = 0u;
+    if (blockIdx.x == 0)
+        for (uint32_t k = threadIdx.x; k < iso_count; k += blockDim.x) {
+            heads[k] = 0u;
+            if (stats) {
+                vr_render_stats z = { 0, 0, 0, frame_pixels - *n_active_ptr, 0, 0, 0 };
+                stats[k] = z;
+            }
+        }
+}
+
 /* The iso values that left the union walk: each is traced on its own from its own state (the checks and the MOVE of
  * the round that parked it are counted already, its escape helps of that MOVE come with the record). */
 __global__ __launch_bounds__(64) void vr_k_union_fix(VrViewK v, const uint32_t *__restrict__ nodes, const float4 *__restrict__ ray_dt,
                                                      const uint32_t *__restrict__ ray_pix, const uint32_t *__restrict__ n_active_ptr,
                                                      const VrUnionRecord *__restrict__ list, uint32_t cap, uint32_t iso_begin,
                                                      uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
-                                                     uint32_t stack_rows, uint32_t n_top)
+                                                     uint32_t stack_rows, uint32_t n_top, uint32_t *__restrict__ heads, uint32_t iso_count)
 {
+    if (n_active_ptr[kUnionRedoWord]) { union_redo_clear(n_active_ptr, heads, iso_count, frame_pixels, rgb, stats); return; }
     uint32_t count = n_active_ptr[32];
     count = count < cap ? count : cap;
     if (blockIdx.x >= count) return; /* nearly every block of nearly every launch */
@@ -1907,9 +1945,11 @@ __global__ __launch_bounds__(64) void vr_k_union_fix(VrViewK v, const uint32_t *
 __global__ __launch_bounds__(64) void vr_k_union_fix_wide(VrViewK v, const uint32_t *__restrict__ nodes, const float4 *__restrict__ ray_dt,
                                                           const uint32_t *__restrict__ ray_pix, const uint32_t *__restrict__ n_active_ptr,
                                                           const VrUnionRecord *__restrict__ list, uint32_t cap, uint32_t iso_begin,
-                                                          uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats)
+                                                          uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
+                                                          uint32_t *__restrict__ heads, uint32_t iso_count)
 {
     __shared__ uint32_t s_path[VR_WIDE_MAX_DEPTH * 64u];
+    if (n_active_ptr[kUnionRedoWord]) { union_redo_clear(n_active_ptr, heads, iso_count, frame_pixels, rgb, stats); return; }
     uint32_t count = n_active_ptr[32];
     count = count < cap ? count : cap;
     LdsPath<64u> path{ s_path + threadIdx.x };
@@ -2321,6 +2361,26 @@ static hipError_t lpt_prepare(hipStream_t stream, int lpt_mode, void *workspace,
     return hipSuccess;
 }
 
+/* Runs of iso values that may leave the union walks of one call and be finished by vr_k_union_fix: what the list behind the
+ * queue heads holds.  VR_UNION_EXCEPT_CAP in the environment lowers it (tests of the full list: the call is rendered again). */
+static uint32_t union_except_cap()
+{
+    const char *env = getenv("VR_UNION_EXCEPT_CAP");
+    if (!env) return VR_UNION_EXCEPT_CAP;
+    const long v = atol(env);
+    return v < 1 ? 1u : (v > (long)VR_UNION_EXCEPT_CAP ? VR_UNION_EXCEPT_CAP : (uint32_t)v);
+}
+
+/* VR_UNION_FORCE_REDO=1 in the environment (tests): the word that makes the fix kernel clear the call's outputs and the sweep
+ * kernel render it again is set behind every union launch, as the union kernel sets it when its list is full -- which no
+ * volume tried so far comes near (a lane keeps three states of runs that left its front, idle lanes take them over). */
+static hipError_t union_force_redo(hipStream_t stream, uint32_t *n_active)
+{
+    const char *env = getenv("VR_UNION_FORCE_REDO");
+    if (!env || !atoi(env)) return hipSuccess;
+    return hipMemsetD32Async((hipDeviceptr_t)(n_active + kUnionRedoWord), 1, 1, stream);
+}
+
 /* levels of the tree a persistent block keeps in LDS: what is left of the CU's 160 KiB beside the path stacks (and
  * the sweep kernel's counters), at most 14 */
 static uint32_t lds_top_levels(uint32_t max_depth, uint64_t n_slots, size_t stat_bytes)
@@ -2414,14 +2474,16 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     const uint32_t stack_rows = stack_levels + 1u;
     /* counters of a short iso range: per-wave slots, summed by a small kernel behind the traversal */
     WaveStats *slots = !sweep && d_stats && iso_count <= kSlotIsoMax && blocks * (kTraceThreads / 64u) <= kSlotWaveMax ? pp.slots : nullptr;
+    const uint32_t *run_always = nullptr;
     void *args_sweep[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
-                           (void *)&d_rgb, (void *)&d_stats, (void *)&taps, (void *)&sweep_items_per_lane, (void *)&launch_seq };
+                           (void *)&d_rgb, (void *)&d_stats, (void *)&taps, (void *)&sweep_items_per_lane, (void *)&launch_seq,
+                           (void *)&run_always };
     void *args_trace[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                            (void *)&d_rgb, (void *)&d_stats, (void *)&slots, (void *)&taps };
     VrUnionRecord *except_list = (VrUnionRecord *)((char *)heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
-    uint32_t except_cap = VR_UNION_EXCEPT_CAP;
+    uint32_t except_cap = union_except_cap();
     void *args_union[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                            (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
@@ -2489,11 +2551,24 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     }
 #endif
     if (use_union) { /* the few iso values whose own MOVE parted from the front's */
+        if ((e = union_force_redo(stream, n_active)) != hipSuccess) return e;
         const uint32_t fix_top = n_top < (1u << 13) ? n_top : (1u << 13); /* 32 KiB of top levels beside the wave's stack */
         hipLaunchKernelGGL(vr_k_union_fix, dim3(2048), dim3(64), ((size_t)stack_rows * 64u + fix_top) * sizeof(uint32_t), stream, view,
                            d_nodes_prepared, ray_dt, ray_pix, n_active, except_list, except_cap, iso_begin, frame_pixels, d_rgb, d_stats,
-                           stack_rows, fix_top);
+                           stack_rows, fix_top, heads, iso_count);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+        /* ... and, should the union kernel have given up (its list full, a front past its bound), the whole call once more with
+         * the kernel that shares traversals between iso values: it leaves at once unless kUnionRedoWord is set */
+        const size_t redo_stat = (size_t)sweep_stat_words(iso_count) * sizeof(uint32_t);
+        const uint32_t redo_top = 1u << lds_top_levels(max_depth, view.n_slots, redo_stat);
+        const uint32_t *run_if = n_active + kUnionRedoWord;
+        const uint32_t redo_ipl = VR_SWEEP_ITEMS_DEFAULT, redo_seq = 0u;
+        const VrTapsK no_taps = { nullptr, nullptr, nullptr, nullptr };
+        void *args_redo[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&redo_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
+                              (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
+                              (void *)&d_rgb, (void *)&d_stats, (void *)&no_taps, (void *)&redo_ipl, (void *)&redo_seq, (void *)&run_if };
+        if ((e = hipLaunchKernel((const void *)vr_k_sweep<false, SweepNarrow>, dim3(blocks), dim3(kTraceThreads), args_redo,
+                                 (size_t)redo_top * sizeof(uint32_t) + trace_stack_bytes + redo_stat, stream)) != hipSuccess) return e;
     }
     if (slots) {
         hipLaunchKernelGGL(vr_k_sum_slots, dim3(iso_count), dim3(1024), 0, stream, slots, blocks * (kTraceThreads / 64u), d_stats);
@@ -2612,7 +2687,7 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
         const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
         VrUnionRecord *except_list = (VrUnionRecord *)((char *)pp.heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
-        uint32_t except_cap = VR_UNION_EXCEPT_CAP;
+        uint32_t except_cap = union_except_cap();
         void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&stack_rows, (void *)&pp.ray_dt, (void *)&pp.ray_pix,
                          (void *)&pp.n_active, (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
                          (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
@@ -2621,9 +2696,19 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         if ((e = hipLaunchKernel((const void *)vr_k_union<UnionWide>, dim3(blocks), dim3(kTraceThreads), args, lds, stream)) != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
+        if ((e = union_force_redo(stream, pp.n_active)) != hipSuccess) return e;
         hipLaunchKernelGGL(vr_k_union_fix_wide, dim3(2048), dim3(64), 0, stream, view, d_nodes, pp.ray_dt, pp.ray_pix, pp.n_active,
-                           except_list, except_cap, iso_begin, frame_pixels, d_rgb, d_stats);
-        return hipGetLastError();
+                           except_list, except_cap, iso_begin, frame_pixels, d_rgb, d_stats, pp.heads, iso_count);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        /* the whole call once more with the sweep kernel, should the union kernel have given up (see vr_launch_render) */
+        const uint32_t *run_if = pp.n_active + kUnionRedoWord;
+        const uint32_t redo_ipl = VR_SWEEP_ITEMS_DEFAULT, redo_seq = 0u;
+        const VrTapsK no_taps = { nullptr, nullptr, nullptr, nullptr };
+        void *args_redo[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&stack_rows, (void *)&pp.ray_dt, (void *)&pp.ray_pix,
+                              (void *)&pp.n_active, (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
+                              (void *)&d_rgb, (void *)&d_stats, (void *)&no_taps, (void *)&redo_ipl, (void *)&redo_seq, (void *)&run_if };
+        return hipLaunchKernel((const void *)vr_k_sweep<false, SweepWide>, dim3(blocks), dim3(kTraceThreads), args_redo,
+                               ((size_t)stack_rows * kTraceThreads + sweep_stat_words(iso_count)) * sizeof(uint32_t), stream);
     }
     if (sweep) {
         const uint32_t n_top = 0u, stack_rows = VR_WIDE_MAX_DEPTH;
@@ -2631,9 +2716,11 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
         const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
         const void *fn = any_tap ? (const void *)vr_k_sweep<true, SweepWide> : (const void *)vr_k_sweep<false, SweepWide>;
+        const uint32_t *run_always = nullptr;
         void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&stack_rows, (void *)&pp.ray_dt, (void *)&pp.ray_pix,
                          (void *)&pp.n_active, (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
-                         (void *)&d_rgb, (void *)&d_stats, (void *)&taps, (void *)&sweep_items_per_lane, (void *)&launch_seq };
+                         (void *)&d_rgb, (void *)&d_stats, (void *)&taps, (void *)&sweep_items_per_lane, (void *)&launch_seq,
+                         (void *)&run_always };
         if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
         if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, lds, stream)) != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
