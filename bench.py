@@ -13,13 +13,13 @@ rays count, including the ones that miss the volume -- the reference's ms/frame 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`
 (one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE from the environment).  The path shards with no
 data-path collective: every rank holds a replica of the node array.
-  weak   (what `auto` picks) each rank renders a whole sweep of its own; the job is N sweeps
-  strong ONE sweep is split over the ranks: the rows of every frame in bands of 32 dealt out round-robin
-         (--shard bands, the split that keeps every rank's load equal and the sharing of traversals between iso
-         values intact), contiguous blocks of rows (rows), or blocks of iso values (iso)
+  strong (what `auto` picks) ONE sweep is split over the ranks: blocks of iso values (--shard iso, the default: the
+         0..255 sweep of the reference sharded by iso value), the rows of every frame in bands of 32 dealt out round-robin
+         (bands), or contiguous blocks of rows (rows)
+  weak   each rank renders a whole sweep of its own; the job is N sweeps
 For N > 1 the line carries the main figure (`value`, the scaling named in `scaling`) and, unless --no-extras,
-the other ones measured in the same run: `strong_scaling` (or `weak_scaling`), and `strong_with_gather` (the split
-sweep with the framebuffers gathered to rank 0 over RCCL inside the timed region -- the one real exchange step).
+the other ones measured in the same run: `weak_scaling` (or `strong_scaling`), `strong_bands`, and `strong_with_gather`
+(the split sweep with the framebuffers gathered to rank 0 over RCCL inside the timed region -- the one real exchange step).
 
 Inputs (node array) and outputs (RGB24 frames) are resident in HBM across the timed region; `value_host_delivered`
 (N = 1) is the same sweep delivered into page-locked host memory by vr_render_sweep, which is what the
@@ -31,7 +31,11 @@ src/raytrace.zig:162,177, plus one RGB24 store per pixel, :54-67), its duration 
 events on the launch stream.  Next to that contract figure it reports what the kernel really does: the sweep
 kernel's own count of traversals and the share of its run time after its queue ran empty (live, from the kernel),
 and HBM traffic / VALU lane utilisation from the committed rocprofv3 counter pass of the same workload
-(profiles/r02_pmc_<workload>.json), flagged `counters_stale` when the kernel sources have changed since.
+(profiles/r03_pmc_<workload>.json), flagged `counters_stale` when the kernel sources have changed since.  Because the
+union kernel reads ~45 times fewer nodes than the reference checks, `frac` is a work ratio; the line therefore also carries
+the floors a step can be held against: `hbm_floor_ms` (the frames written once plus the kernel's own HBM reads at the HBM
+peak), `latency_floor_ms` (the longest single (ray, iso value) walk of the sweep, timed alone with the per-iso kernel: no
+cut of the iso range gets a launch below it) and `bound`, which names the larger of the two.
 `cpu_baseline` times the CPU oracle (a port of the reference's single-threaded path; the Zig reference cannot be
 built offline) on one host core on a bounded sample of the same workload; `cpu_all_cores` is the same oracle
 with the image rows spread over the host cores this job may use -- a whole-socket figure the reference itself
@@ -131,11 +135,16 @@ def copy_ceiling_gbps(torch):
 def profile_counters(workload, kernel, kernel_ms):
     """HBM traffic and VALU figures of the committed counter pass of this workload, with the fingerprint of the
     kernel sources they were taken on; stale = the sources of the tree this runs in differ."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload)
-    try:
-        s = json.load(open(path))
-        k = s["kernels"][kernel]
-    except (OSError, ValueError, KeyError):
+    s = k = path = None
+    for rnd in ("r03", "r02"):  # the newest committed pass of this workload
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, workload))
+        try:
+            s = json.load(open(path))
+            k = s["kernels"][kernel]
+            break
+        except (OSError, ValueError, KeyError):
+            s = k = None
+    if k is None:
         return None, None, None
     out = {"source": os.path.relpath(path, ROOT), "kernel_sources_sha": s.get("kernel_sources_sha"),
            "commit": s.get("commit")}
@@ -145,6 +154,8 @@ def profile_counters(workload, kernel, kernel_ms):
         # rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies the 128-byte fabric read requests at 64 bytes
         # each, so it is doubled; per launch
         traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        out["hbm_read_bytes"] = 2.0 * k["FETCH_SIZE"] * 1024.0
+        out["hbm_write_bytes"] = k["WRITE_SIZE"] * 1024.0
     if "SQ_ACTIVE_INST_VALU" in k and "GRBM_GUI_ACTIVE" in k:
         simd_quanta = k["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0  # cycles per XCD / 4-cycle issue slots x 1024 SIMDs
         out["valu_busy_frac"] = k["SQ_ACTIVE_INST_VALU"] / simd_quanta
@@ -157,15 +168,52 @@ def profile_counters(workload, kernel, kernel_ms):
     return out, traffic, stale
 
 
+def longest_walk(L, C, torch, capi, r, view, W, H, I0, IN, stream):
+    """The sweep's longest single (ray, iso value) walk, timed alone: every iso value is rendered once by the kernel with one
+    traversal per ray and iso value with the per-pixel check counts (the reference's RayRes.checked_nodes) tapped, the pixel
+    with the most checks is found on the device, and the image row that holds it is then rendered for that iso value alone --
+    a launch with about one ray per wave of a few CUs, whose kernel time is the latency of that walk (plus the launch and the
+    LDS fill).  No cut of the iso range and no scheduling gets a sweep's launch below this."""
+    sp = C.c_void_p(stream.cuda_stream)
+    d_rgb = torch.empty((1, H, W, 3), dtype=torch.uint8, device="cuda")
+    d_chk = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    taps = capi.Taps(None, None, d_chk.data_ptr(), None)
+    capi.check(L.vr_set_kernel(r.handle, capi.KERNEL_PIPELINE), "vr_set_kernel")
+    best = torch.zeros(256, dtype=torch.int32, device="cuda")
+    where = torch.zeros(256, dtype=torch.int64, device="cuda")
+    with torch.cuda.stream(stream):
+        for iso in range(I0, I0 + IN):
+            capi.check(L.vr_render_device(r.handle, C.byref(view), iso, 1, 0, H, d_rgb.data_ptr(), None, C.byref(taps), sp), "vr_render_device")
+            m, at = d_chk.view(-1).max(0)
+            best[iso], where[iso] = m, at
+    torch.cuda.synchronize()
+    iso = int(best.argmax().item())
+    checks, at = int(best[iso].item()), int(where[iso].item())
+    y, x = divmod(at, W)
+    capi.check(L.vr_set_timing(r.handle, 1), "vr_set_timing")
+    tot, n = C.c_double(), C.c_uint32()
+    times = []
+    for i in range(12):
+        with torch.cuda.stream(stream):
+            capi.check(L.vr_render_device(r.handle, C.byref(view), iso, 1, y, y + 1, d_rgb.data_ptr(), None, None, sp), "vr_render_device")
+        torch.cuda.synchronize()
+        capi.check(L.vr_timing_read(r.handle, C.byref(tot), C.byref(n)), "vr_timing_read")
+        if i >= 2:
+            times.append(tot.value / max(1, n.value))
+    capi.check(L.vr_set_timing(r.handle, 0), "vr_set_timing")
+    return {"ms": min(times), "iso": iso, "pixel": [x, y], "checks": checks,
+            "how": "kernel time of image row %d alone at iso %d with the one-traversal-per-iso kernel (min of 10)" % (y, iso)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
-                    help="auto: weak (one sweep per rank), with the strong figures (one sweep split over the ranks) as extras")
-    ap.add_argument("--shard", choices=["bands", "rows", "iso"], default="bands",
-                    help="strong scaling: rows in bands of 32 dealt out round-robin (default), contiguous row blocks, or iso blocks")
+                    help="auto: strong (ONE sweep split over the ranks), with the weak figure (one sweep per rank) as an extra")
+    ap.add_argument("--shard", choices=["bands", "rows", "iso"], default="iso",
+                    help="strong scaling: blocks of iso values (default), rows in bands of 32 dealt out round-robin, or contiguous row blocks")
     ap.add_argument("--gather", action="store_true", help="gather the framebuffers to rank 0 inside the timed region of the main figure")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: only the main figure, not the other scaling / the gather variant")
     ap.add_argument("--kernel", type=int, default=0)
@@ -175,6 +223,7 @@ def main():
     ap.add_argument("--iso-count", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-first-call", action="store_true", help="profiling runs: every launch of the run is a timed-step launch")
+    ap.add_argument("--no-latency-floor", action="store_true", help="skip the search for the sweep's longest single walk (256 short launches)")
     ap.add_argument("--no-host-delivered", action="store_true",
                     help="skip the host-delivered leg (profiling runs: its shorter launches would mix into the kernel statistics)")
     ap.add_argument("--settle", type=int, default=24,
@@ -213,9 +262,11 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    # auto: every rank renders its own sweep (the units of the job are sharded over the ranks, nothing is exchanged:
-    # weak scaling), and the one-sweep-split-over-the-ranks figures ride along as extras in the same line
-    scaling = args.scaling if args.scaling != "auto" else "weak"
+    # auto: ONE sweep split over the ranks by iso value (strong scaling: the reference's 0..255 sweep sharded over the GPUs of
+    # a node); a sweep per rank (weak scaling: a stream of sweeps) and the other splits ride along as extras in the same line
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+    if args.shard == "iso" and args.iso_count < world:
+        args.shard = "bands"  # fewer frames than ranks (one large frame): the rows are split instead
     if args.in_flight < 1 or (args.in_flight > 1 and (args.gather or world > 1)):
         raise SystemExit("--in-flight must be >= 1 and goes with one GPU and no gather")
 
@@ -260,6 +311,7 @@ def main():
             self.iso_begin, self.iso_count, self.bands = I0, IN, None
             self.row_begin, self.row_end = 0, H
             self.row_lists = None
+            self.gatherer = None
             if mode == "strong" and world > 1:
                 if shard == "iso":
                     self.iso_begin, self.iso_count = sharding.iso_shard(rank, world, I0, IN)
@@ -288,12 +340,17 @@ def main():
                                               self.row_end, rgb.data_ptr(), stats.data_ptr(), None, s), "vr_render_device")
 
         def gather(self):
+            """Framebuffers to rank 0: grouped isend / irecv straight into one preallocated [iso, H, W, 3] tensor (iso shards)
+            or into one staging buffer per rank and one indexed copy (row shards); built once, allocates nothing per step."""
             local = self.d_rgb.cpu() if rehearsal else self.d_rgb
-            if self.row_lists is not None:
-                return sharding.gather_rows(local, self.row_lists, H, dst=0)
-            if self.mode == "strong" and self.shard == "iso":
-                return sharding.gather_frames(local, self.counts, dst=0)
-            return sharding.gather_frames(local, [IN] * world, dst=0)
+            if self.gatherer is None:
+                if self.row_lists is not None:
+                    self.gatherer = sharding.FrameGather(local, row_lists=self.row_lists, height=H, dst=0)
+                elif self.mode == "strong" and self.shard == "iso":
+                    self.gatherer = sharding.FrameGather(local, counts=self.counts, dst=0)
+                else:
+                    self.gatherer = sharding.FrameGather(local, counts=[IN] * world, dst=0)
+            return self.gatherer(local)
 
         def describe(self):
             if world == 1:
@@ -397,13 +454,16 @@ def main():
 
     extras = {}
     if world > 1 and not args.no_extras:
-        for name, plan, gather in (("weak_scaling", Plan("weak", args.shard), False),
-                                   ("strong_scaling", Plan("strong", args.shard), False),
-                                   ("strong_with_gather", Plan("strong", args.shard), True)):
+        other = "bands" if args.shard != "bands" else "iso"
+        for name, mk, gather in (("weak_scaling", lambda: Plan("weak", args.shard), False),
+                                 ("strong_scaling", lambda: Plan("strong", args.shard), False),
+                                 ("strong_" + other, lambda: Plan("strong", other), False),
+                                 ("strong_with_gather", lambda: Plan("strong", args.shard), True)):
             if (name == "weak_scaling" and scaling == "weak" and not args.gather) or \
                (name == "strong_scaling" and scaling == "strong" and not args.gather) or \
                (name == "strong_with_gather" and scaling == "strong" and args.gather):
                 continue  # that is the main figure
+            plan = mk()
             dt_x, rays_x, kms_x, _ = measure(plan, gather)
             extras[name] = {"value": rays_x * args.steps / dt_x / 1e6, "unit": "Mrays/s", "ms_per_step": dt_x / args.steps * 1e3,
                             "kernel_ms_rank0": kms_x, "sharding": plan.describe(), "gather": gather,
@@ -459,40 +519,81 @@ def main():
         }
         if info:
             out["roofline"].update(info)
+        rf = out["roofline"]
+        # What a step can be held against.  The frames are written once whatever the kernel does (3 B x pixels x iso values), and
+        # the kernel's own reads come from HBM as far as the counter pass saw them: at the HBM peak that is the step's floor.
+        frame_bytes = 3.0 * main_plan.rays
+        own_reads = (counters or {}).get("hbm_read_bytes") or 0.0
+        rf["hbm_floor_ms"] = (frame_bytes + own_reads) / (HBM_PEAK_GBS * 1e9) * 1e3
+        rf["hbm_floor_bytes"] = {"frames_written_once": frame_bytes, "kernel_hbm_reads_counter_pass": own_reads or None}
+        rf["step_over_hbm_floor"] = out["ms_per_step"] / rf["hbm_floor_ms"] if rf["hbm_floor_ms"] > 0 else None
+        rf["infinity_cache"] = ("hit rate not measured: rocprofv3 exposes no Infinity Cache (MALL) counter on gfx950; FETCH_SIZE / "
+                                "TCC_EA0_RDREQ count the L2's requests to the fabric, in front of that cache")
+        if world == 1 and not wide and sweep_kernel and not args.no_latency_floor and args.in_flight == 1:
+            lw = longest_walk(L, C, torch, capi, r, view, W, H, I0, IN, stream)
+            r.set_kernel(args.kernel)
+            rf["latency_floor_ms"] = lw["ms"]
+            rf["latency_floor"] = lw
+            rf["kernel_over_latency_floor"] = kernel_ms / lw["ms"] if lw["ms"] > 0 else None
+            if lw["ms"] > rf["hbm_floor_ms"]:
+                rf["bound"] = "latency"
+                rf["bound_note"] = ("the launch cannot end before its longest single (ray, iso value) walk does, and that walk alone takes "
+                                    "longer than moving the step's bytes at the HBM peak: `frac` (contract: algorithmic bytes / kernel "
+                                    "time / 8 TB/s) stays a work ratio, hbm_traffic_frac is what HBM itself carries")
         out.update(extras)
         if rehearsal:
             out["rehearsal"] = "all ranks on one GPU over gloo: control-flow check only, not a measurement"
         if wide:
             out["build_ms_gpu"] = build_ms  # the host builder and the CPU oracle cannot run at this size
         if (world == 1 and info and (info.get("tiles_longest_first") or os.environ.get("VR_BENCH_FIRST_CALL")) and not main_plan.bands
-                and args.in_flight == 1 and not args.no_first_call):
-            # The timed steps repeat one call, and from its second launch on such a call starts its tiles longest first.
-            # What a caller gets who renders a view once: the same call right after a different call on the context (a small
-            # one: 8 rows), one launch at a time, next to the repeated call timed the same way.
-            def one(first):
-                if first:
-                    with torch.cuda.stream(stream):
-                        capi.check(L.vr_render_device(r.handle, C.byref(view), I0, min(8, IN), 0, min(8, H), main_plan.d_rgb.data_ptr(),
-                                                      None, None, C.c_void_p(stream.cuda_stream)), "vr_render_device")
-                    torch.cuda.synchronize()
+                and args.in_flight == 1 and not args.no_first_call and IN >= 9):
+            # The timed steps repeat one call, and a call the context remembers starts its tiles longest first, with the cut
+            # of the iso range it has settled on.  What a caller gets who renders a view ONCE: a context that has never seen
+            # the call (a fresh one per sample; its scratch is allocated by a call with one iso value less, which is another
+            # workload and another call to the context), one launch, synchronised.
+            def timed_call(rr):
                 tot, n = C.c_double(), C.c_uint32()
-                capi.check(L.vr_timing_read(r.handle, C.byref(tot), C.byref(n)), "vr_timing_read")  # drop what came before
+                capi.check(L.vr_timing_read(rr.handle, C.byref(tot), C.byref(n)), "vr_timing_read")  # drop what came before
                 t0 = time.perf_counter()
                 with torch.cuda.stream(stream):
-                    main_plan.render(r, main_plan.d_rgb, main_plan.d_stats, C.c_void_p(stream.cuda_stream))
+                    capi.check(L.vr_render_device(rr.handle, C.byref(view), I0, IN, 0, H, main_plan.d_rgb.data_ptr(),
+                                                  main_plan.d_stats.data_ptr(), None, C.c_void_p(stream.cuda_stream)), "vr_render_device")
                 torch.cuda.synchronize()
                 dt1 = time.perf_counter() - t0
-                capi.check(L.vr_timing_read(r.handle, C.byref(tot), C.byref(n)), "vr_timing_read")
+                capi.check(L.vr_timing_read(rr.handle, C.byref(tot), C.byref(n)), "vr_timing_read")
                 return dt1 * 1e3, tot.value / max(1, n.value)
+
+            def first_sample():
+                with vr.Renderer(local_rank) as rr:
+                    rr.upload_volume(data)
+                    rr.build_kdt("AlwaysCenter")
+                    rr.set_kernel(args.kernel)
+                    with torch.cuda.stream(stream):
+                        capi.check(L.vr_render_device(rr.handle, C.byref(view), I0, IN - 1, 0, H, main_plan.d_rgb.data_ptr(), None, None,
+                                                      C.c_void_p(stream.cuda_stream)), "vr_render_device")
+                    torch.cuda.synchronize()
+                    capi.check(L.vr_set_timing(rr.handle, 1), "vr_set_timing")
+                    return timed_call(rr)
+
+            def other_then_repeat():
+                with torch.cuda.stream(stream):  # a different call in between: the context remembers the timed steps' call across it
+                    capi.check(L.vr_render_device(r.handle, C.byref(view), I0, min(8, IN), 0, min(8, H), main_plan.d_rgb.data_ptr(),
+                                                  None, None, C.c_void_p(stream.cuda_stream)), "vr_render_device")
+                torch.cuda.synchronize()
+                return timed_call(r)
+
+            firsts = sorted(first_sample() for _ in range(7))
             capi.check(L.vr_set_timing(r.handle, 1), "vr_set_timing")
-            firsts = sorted(one(True) for _ in range(7))
-            repeats = sorted(one(False) for _ in range(7))
+            repeats = sorted(timed_call(r) for _ in range(7))
+            others = sorted(other_then_repeat() for _ in range(7))
             capi.check(L.vr_set_timing(r.handle, 0), "vr_set_timing")
             out["first_call"] = {"ms_per_step": firsts[3][0], "kernel_ms": sorted(k for _, k in firsts)[3],
                                  "value": rays_per_step / (firsts[3][0] * 1e-3) / 1e6,
                                  "repeated_call_same_way_ms": repeats[3][0],
-                                 "note": "medians of 7 single launches, each synchronised; first = right after a different call on "
-                                         "the context (tiles in list order), repeated = the timed steps' call again"}
+                                 "repeated_after_another_call_ms": others[3][0],
+                                 "note": "medians of 7 single launches, each synchronised; first = the call on a context that has never "
+                                         "seen it (tiles ordered by their rays' chords, base cut of the iso range), repeated = the timed "
+                                         "steps' call again, after another call = the same with a different call on the context in between"}
         if world == 1 and not wide and not args.no_host_delivered and IN * W * H * 3 <= (1 << 30):
             # the sweep as the reference's caller gets it: frames in host memory (page-locked), src/main.zig:119-135
             try:

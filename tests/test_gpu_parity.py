@@ -579,7 +579,11 @@ def test_bench_line_has_the_contract_fields():
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in d["roofline"], key
-    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    assert d["roofline"]["bound"] in ("hbm", "latency") and d["roofline"]["peak"] == 8000.0
+    # the floors a step can be held against: the frames written once at the HBM peak, and the sweep's longest single walk
+    assert 0 < d["roofline"]["hbm_floor_ms"] < d["ms_per_step"] and d["roofline"]["step_over_hbm_floor"] > 1
+    assert 0 < d["roofline"]["latency_floor_ms"] <= d["roofline"]["kernel_ms"] * 1.05 and d["roofline"]["latency_floor"]["checks"] > 100
+    assert d["roofline"]["bound"] == ("latency" if d["roofline"]["latency_floor_ms"] > d["roofline"]["hbm_floor_ms"] else "hbm")
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-9
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in d["cpu_baseline"], key
@@ -589,6 +593,7 @@ def test_bench_line_has_the_contract_fields():
     # once is reported next to it
     assert d["roofline"]["tiles_longest_first"] is True
     assert d["first_call"]["ms_per_step"] > 0 and d["first_call"]["kernel_ms"] > 0 and d["first_call"]["value"] > 0
+    assert d["first_call"]["repeated_after_another_call_ms"] > 0
 
 
 SPAN_HEURISTICS = ["MinimizeSpan", "FlexibleFirst5", "FlexibleFirst10", "FlexibleAfter10", "FlexibleAfter15",

@@ -6,7 +6,7 @@ export VR_BENCH_REHEARSAL=1
 out=gpurun_out/rehearsal
 mkdir -p $out
 i=0
-for args in "--gpus 2" "--gpus 4 --scaling strong --shard rows --gather --no-extras" "--gpus 3 --scaling strong --shard iso" "--gpus 2 --scaling weak --no-extras" \
+for args in "--gpus 2" "--gpus 4 --scaling strong --shard rows --gather --no-extras" "--gpus 3 --scaling strong --shard bands" "--gpus 2 --scaling weak --no-extras" \
             "--gpus 4 --scaling strong --width 4096 --iso-begin 80 --iso-count 1 --gather --no-extras" \
             "--gpus 2 --scaling strong --shard rows --volume gyroid1024 --width 2048 --iso-begin 140 --iso-count 1 --no-extras"; do
   i=$((i+1))
@@ -17,6 +17,6 @@ for args in "--gpus 2" "--gpus 4 --scaling strong --shard rows --gather --no-ext
 import json
 d=json.loads(open("$out/run$i.json").read().strip().splitlines()[-1])
 print("$args ->", d["n_gpus"], d["scaling"], d["config"]["sharding"], "gather", d["config"]["gather"], "rays/step", d["config"]["rays_per_step"], "errors", d["errors"], "%.1f Mrays/s" % d["value"],
-      {k: (round(d[k]["value"]), d[k]["rays_per_step"]) for k in ("weak_scaling", "strong_scaling", "strong_with_gather") if k in d})
+      {k: (round(d[k]["value"]), d[k]["rays_per_step"]) for k in ("weak_scaling", "strong_scaling", "strong_bands", "strong_iso", "strong_with_gather") if k in d})
 PY
 done

@@ -52,45 +52,64 @@ struct vr_ctx {
     uint32_t last_ipl = 0; /* items per lane of the last sweep-kernel launch (0: one traversal per ray, nothing to cut) */
     bool ranges_nested = true; /* node ranges nested along every path: built trees always, uploaded ones when checked so */
     size_t info_off = 0; /* where the last sweep-kernel launch in d_work left its report; 0 = none yet */
-    size_t order_flag_off = 0; /* where its pre-pass said whether it ordered the tiles; 0 = it was not asked to */
-    /* The sweep kernel's cut of the iso range, tuned per workload from its own reports.  Every sweep launch in the
-     * context's scratch is tagged with a sequence number and followed by an asynchronous copy of its report into
-     * page-locked memory; a later launch reads whatever report has arrived (it never waits).  Fewer, longer items
-     * share more of their walks and balance worse; where the best trade lies depends on the volume.  Single launches
-     * scatter by several per cent (which CU gets which item is decided by atomics), so a cut is judged by the shortest
-     * of three launches.  For a new workload (tree, image size, iso range) the base cut runs first (8 items per lane
-     * for long sweeps, fewer for short ones: sweep_cut_base; the very first launch, on cold caches, does not count),
-     * then the next smaller cut (3/4 of the base) and the next larger one (3/2), and on from the better of the two
-     * (1/2, 1/4 or 2x, 4x) while it pays.  A candidate gets exactly three launches, all other launches use the best
-     * cut known; it stays when it was at least 1.5 % shorter.  Results never depend on the cut.  The kernel with one
-     * traversal per ray and block of iso values is tuned the same way from a smaller base. */
+    const void *order_flag = nullptr; /* where its pre-pass said whether it ordered the tiles; null = it was not asked to */
+    /* The sweep kernels' cut of the iso range, tuned per workload from their own reports.  Every sweep launch in the
+     * context's scratch is tagged and followed by an asynchronous copy of its report into page-locked memory; a later
+     * launch reads whatever report has arrived (it never waits) and credits it to the workload that launched it.  Fewer,
+     * longer items share more of their walks and balance worse; where the best trade lies depends on the volume.  Single
+     * launches scatter by several per cent (which CU gets which item is decided by atomics), so a cut is judged by the
+     * shortest of a few launches (three; two for the kernel with one traversal per ray, whose cut matters less).  For a new
+     * workload the base cut runs first (8 items per lane for long sweeps, 3 for the union kernel, fewer for short sweeps:
+     * sweep_cut_base; the very first launch, on cold caches, does not count), then the next smaller cut (3/4 of the base)
+     * and the next larger one (3/2), and on from the better of the two (1/2, 1/4 or 2x, 4x) while it pays.  A candidate gets
+     * exactly its launches, all other launches use the best cut known; it stays when it was at least 1.5 % shorter.  Results
+     * never depend on the cut.
+     * A workload is what decides the cut: tree, image size, number of rows and of iso values, kernel -- not the camera, the
+     * first row or the first iso value, so that the chunks of one sweep and the views of one scene share what was learnt.
+     * The context remembers the last kRemember workloads. */
     struct SweepTune {
-        uint64_t key = 0;
-        uint32_t seq = 0, seen = 0;
+        uint32_t seq = 0;        /* launches of this workload so far */
         uint32_t base = VR_SWEEP_ITEMS_DEFAULT, best_ipl = VR_SWEEP_ITEMS_DEFAULT;
         uint64_t best_span = 0;
         int dir = 0, step = 0;   /* candidate being tried: sweep_cut_candidate(base, dir, step) */
         bool down_better = false; /* the first step down beat the base */
         int phase = 0;           /* 0 measuring the default, 1 trying candidates, 2 settled */
+        int samples = 3;         /* launches a cut is judged by */
         int n_launched = 0, n_reports = 0; /* of the cut being measured */
         uint32_t last_seq = 0;             /* its newest launch */
         uint64_t cur_span = ~0ull;         /* its shortest launch so far */
-        uint32_t ipl_of_seq[16] = { 0 };
-    } tune;
-    /* The last call that ran in d_work, if it was one of the kernel with one traversal per ray: that kernel leaves, per tile
-     * of 64 rays, the length of the tile's longest item behind the workspace, and the next call that is the same in every
-     * respect (tree, view, rows, iso range) starts its tiles longest first.  Any other call in between ends that. */
-    struct LastUnion {
+    };
+    static constexpr int kRemember = 8;
+    struct TuneEntry {
+        uint64_t key = 0, used = 0; /* key 0: free */
+        SweepTune t;
+    } tunes[kRemember];
+    /* the launches whose reports may still arrive: tag -> workload, its launch number, the cut it ran with */
+    struct Sent {
+        uint32_t tag = 0, local_seq = 0, ipl = 0;
+        int slot = -1;
+        uint64_t key = 0;
+    } sent[16];
+    uint32_t tag = 0, tag_seen = 0;
+    int cur_tune = -1; /* the workload of the last sweep launch */
+    /* What the kernel with one traversal per ray leaves for the next launch of the same CALL (tree, view with its camera,
+     * rows, iso range): per tile of 64 rays the length of the tile's longest item, in a device buffer of the call's own, from
+     * which the next launch starts its tiles longest first.  The context remembers the last kRemember calls, so a caller that
+     * alternates between a few views, or renders a sweep in chunks, keeps every one of them in its fast order. */
+    struct LptEntry {
         bool have = false;
+        uint64_t used = 0;
         uint64_t tree_id = 0;
         VrViewK view;
         uint32_t iso_begin = 0, iso_count = 0, row_begin = 0, row_end = 0;
-        void *work = nullptr;
-        /* what lies behind the workspace: lengths kept by a launch with this cut of the iso range (0 = none, the words are
-         * zero), and an order made from the lengths of a launch with this cut (0 = none).  The lengths of a call repeat from
-         * launch to launch, so once the order comes from the cut in use nothing is kept or sorted any more. */
+        /* what the buffer holds: lengths kept by a launch with this cut of the iso range (0 = none, the words are zero), and an
+         * order made from the lengths of a launch with this cut (0 = none).  The lengths of a call repeat from launch to launch,
+         * so once the order comes from the cut in use nothing is kept or sorted any more. */
         uint32_t lengths_ipl = 0, order_ipl = 0;
-    } last_union;
+        void *mem = nullptr;
+        size_t cap = 0;
+    } lpts[kRemember];
+    uint64_t use_clock = 0;
     uint64_t tree_id = 0;                 /* changes with every upload / build */
     unsigned long long *h_info = nullptr; /* page-locked: walks, items, 3 ticks, sequence number */
     /* options */
@@ -229,6 +248,8 @@ void vr_ctx_destroy(vr_ctx *c)
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     free_prepared(c);
     if (c->d_work) (void)hipFree(c->d_work);
+    for (vr_ctx::LptEntry &l : c->lpts)
+        if (l.mem) (void)hipFree(l.mem);
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     if (c->d_stats) (void)hipFree(c->d_stats);
     for (int i = 0; i < 4; i++)
@@ -434,9 +455,8 @@ int vr_download_kdt_wide(vr_ctx *c, uint32_t *nodes_out, uint64_t first_slot, ui
     return VR_OK;
 }
 
-/* Picks the sweep kernel's items-per-lane for this launch and tags it (see vr_ctx::SweepTune). */
-static constexpr int kSweepSamples = 3;
-/* where the search starts: short sweeps have few distinct walks per ray to share, and every cut costs one more */
+/* where the search for a workload's cut starts: short sweeps have few distinct walks per ray to share, and every cut costs
+ * one more */
 static uint32_t sweep_cut_base(uint32_t iso_count, bool union_kernel = false)
 {
     if (union_kernel) { /* one traversal per ray and block: blocks only shorten the longest walk and fill the lanes */
@@ -455,76 +475,96 @@ static uint32_t sweep_cut_candidate(uint32_t base, int dir, int step)
     const uint32_t prev = step == 0 ? base : (base * num[dir < 0 ? 0 : 1][step - 1] + 4u) / 8u;
     return c == prev || c == 0u ? 0u : c;
 }
-static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin,
-                            uint32_t n_rows, uint32_t band_rows, bool union_kernel, uint32_t *ipl_out, uint32_t *seq_out)
+static bool tune_debug()
 {
-    static const bool tune_debug = std::getenv("VR_TUNE_DEBUG") != nullptr; /* VR_TUNE_DEBUG=1: the decisions, on stderr */
-    vr_ctx::SweepTune &t = c->tune;
-    uint64_t key = 1469598103934665603ull; /* FNV-1a over what defines the workload's shape (not the camera) */
-    const uint64_t parts[] = { c->tree_id, view->width, view->height, row_begin, n_rows, band_rows, iso_begin, iso_count, union_kernel };
+    static const bool on = std::getenv("VR_TUNE_DEBUG") != nullptr; /* VR_TUNE_DEBUG=1: the decisions, on stderr */
+    return on;
+}
+
+/* The newest report that has arrived goes to the workload that launched it (see vr_ctx::SweepTune). */
+static void sweep_tune_report(vr_ctx *c)
+{
+    const volatile unsigned long long *h = c->h_info;
+    const uint32_t tag = (uint32_t)h[5];
+    if (tag == 0u || tag == c->tag_seen) return;
+    const unsigned long long t_begin = h[2], t_empty = h[3], t_end = h[4];
+    if ((uint32_t)h[5] != tag) return; /* the next report is landing: read it on the next call */
+    c->tag_seen = tag;
+    const vr_ctx::Sent rec = c->sent[tag & 15u];
+    if (rec.tag != tag || rec.slot < 0 || c->tunes[rec.slot].key != rec.key || t_end <= t_begin) return; /* too old to tell whose it was */
+    vr_ctx::SweepTune &t = c->tunes[rec.slot].t;
+    if (t.phase == 2) return;
+    const uint64_t span = t_end - t_begin;
+    if (tune_debug())
+        std::fprintf(stderr, "[sweep tune] workload %d: report of its launch %u (now at %u): %u items per lane, span %.3f ms, tail %.3f, phase %d\n",
+                     rec.slot, rec.local_seq, t.seq, rec.ipl, (double)span / 1e5, (double)(t_end - (t_empty < t_end ? t_empty : t_end)) / (double)span, t.phase);
+    const uint32_t under_test = t.phase == 0 ? t.base : sweep_cut_candidate(t.base, t.dir, t.step);
+    if (rec.ipl == under_test && rec.local_seq >= 2u) { /* the workload's first launch, on cold caches, does not count */
+        t.cur_span = span < t.cur_span ? span : t.cur_span;
+        t.n_reports++;
+    }
+    if (t.phase == 1 && t.n_launched == t.samples && rec.local_seq >= t.last_seq && t.n_reports < t.samples)
+        t.n_launched = t.n_reports; /* reports overwritten before they were read (the host ran ahead): launch again */
+    if (t.n_reports < t.samples) return;
+    if (t.phase == 0) {
+        t.best_ipl = under_test; t.best_span = t.cur_span;
+        t.dir = sweep_cut_candidate(t.base, -1, 0) ? -1 : 1; t.step = 0;
+        t.phase = 1;
+    } else {
+        const bool better = (double)t.cur_span < 0.985 * (double)t.best_span;
+        if (better) { t.best_ipl = under_test; t.best_span = t.cur_span; }
+        if (t.step == 0 && t.dir < 0) { /* the first step down is in: the first step up is measured as well */
+            t.down_better = better;
+            if (sweep_cut_candidate(t.base, 1, 0)) t.dir = 1;
+            else if (better) t.step = 1;
+            else t.phase = 2;
+        } else if (t.step == 0) {       /* both first steps are in: on in the direction of the best one */
+            if (better) t.step = 1;
+            else if (t.down_better) { t.dir = -1; t.step = 1; }
+            else t.phase = 2;
+        } else if (better) t.step++;
+        else t.phase = 2;
+    }
+    if (t.phase == 1 && !sweep_cut_candidate(t.base, t.dir, t.step)) t.phase = 2;
+    t.n_reports = 0; t.n_launched = 0; t.cur_span = ~0ull;
+}
+
+/* Picks the items-per-lane of this launch from what the context knows about its workload, and tags the launch. */
+static void sweep_tune_next(vr_ctx *c, const vr_view *view, uint32_t iso_count, uint32_t n_rows, uint32_t band_rows, bool union_kernel,
+                            uint32_t *ipl_out, uint32_t *tag_out)
+{
+    sweep_tune_report(c);
+    uint64_t key = 1469598103934665603ull; /* FNV-1a over what decides the cut */
+    const uint64_t parts[] = { c->tree_id, view->width, view->height, n_rows, band_rows, iso_count, union_kernel };
     for (uint64_t p : parts) { key ^= p; key *= 1099511628211ull; }
-    if (key != t.key) {
-        t = vr_ctx::SweepTune();
-        t.key = key;
-        t.base = t.best_ipl = sweep_cut_base(iso_count, union_kernel);
-        c->h_info[5] = 0; /* a report of the previous workload must not be taken for one of this */
+    key |= 1ull; /* 0 means a free slot */
+    int slot = -1, oldest = 0;
+    for (int i = 0; i < vr_ctx::kRemember; i++) {
+        if (c->tunes[i].key == key) slot = i;
+        if (c->tunes[i].used < c->tunes[oldest].used) oldest = i;
     }
-    /* the newest report that has arrived */
-    const unsigned long long *h = c->h_info;
-    const uint32_t got_seq = (uint32_t)h[5];
-    if (t.phase != 2 && got_seq != 0 && got_seq != t.seen && got_seq <= t.seq && t.seq - got_seq < 16u && h[4] > h[2]) {
-        t.seen = got_seq;
-        const uint32_t ipl = t.ipl_of_seq[got_seq & 15u];
-        const uint64_t span = h[4] - h[2];
-        const double tail = (double)(h[4] - (h[3] < h[4] ? h[3] : h[4])) / (double)span;
-        if (tune_debug)
-            std::fprintf(stderr, "[sweep tune] report of launch %u (now at %u): %u items per lane, span %.3f ms, tail %.3f, phase %d\n", got_seq,
-                         t.seq, ipl, (double)span / 1e5, tail, t.phase);
-        const uint32_t under_test = t.phase == 0 ? t.base : sweep_cut_candidate(t.base, t.dir, t.step);
-        if (ipl == under_test && got_seq >= 2u) {
-            t.cur_span = span < t.cur_span ? span : t.cur_span;
-            t.n_reports++;
-        }
-        if (t.phase == 1 && t.n_launched == kSweepSamples && got_seq >= t.last_seq && t.n_reports < kSweepSamples)
-            t.n_launched = t.n_reports; /* reports overwritten before they were read (the host ran ahead): launch again */
-        if (t.n_reports == kSweepSamples) {
-            if (t.phase == 0) {
-                t.best_ipl = under_test; t.best_span = t.cur_span;
-                t.dir = sweep_cut_candidate(t.base, -1, 0) ? -1 : 1; t.step = 0;
-                t.phase = 1;
-            } else {
-                const bool better = (double)t.cur_span < 0.985 * (double)t.best_span;
-                if (better) { t.best_ipl = under_test; t.best_span = t.cur_span; }
-                if (t.step == 0 && t.dir < 0) { /* the first step down is in: the first step up is measured as well */
-                    t.down_better = better;
-                    if (sweep_cut_candidate(t.base, 1, 0)) t.dir = 1;
-                    else if (better) t.step = 1;
-                    else t.phase = 2;
-                } else if (t.step == 0) {       /* both first steps are in: on in the direction of the best one */
-                    if (better) t.step = 1;
-                    else if (t.down_better) { t.dir = -1; t.step = 1; }
-                    else t.phase = 2;
-                } else if (better) t.step++;
-                else t.phase = 2;
-            }
-            if (t.phase == 1 && !sweep_cut_candidate(t.base, t.dir, t.step)) t.phase = 2;
-            t.n_reports = 0; t.n_launched = 0; t.cur_span = ~0ull;
-        }
+    if (slot < 0) {
+        slot = oldest;
+        c->tunes[slot] = vr_ctx::TuneEntry();
+        c->tunes[slot].key = key;
+        vr_ctx::SweepTune &n = c->tunes[slot].t;
+        n.base = n.best_ipl = sweep_cut_base(iso_count, union_kernel);
+        n.samples = union_kernel ? 2 : 3;
     }
+    c->tunes[slot].used = ++c->use_clock;
+    c->cur_tune = slot;
+    vr_ctx::SweepTune &t = c->tunes[slot].t;
     uint32_t ipl = t.best_ipl;
-    const bool cand = t.phase == 1 && t.n_launched < kSweepSamples;
+    const bool cand = t.phase == 1 && t.n_launched < t.samples;
     if (cand) { ipl = sweep_cut_candidate(t.base, t.dir, t.step); t.n_launched++; }
     t.seq++;
-    if (t.seq == 0) t.seq = 1;
-    /* The first launch of a workload does not count for the search (cold caches), and for a caller that renders a view once
-     * it is the only one: it runs with the cut that is best in list order (Skull, first call: 1.40 ms with 2 or 3 items per
-     * lane, 1.56 with 4; C60 1.11 / 1.13 / 1.15), the search starts from the base that finds the best cut of every volume. */
-    if (union_kernel && t.seq == 1u && t.phase == 0 && ipl > VR_UNION_ITEMS_FIRST) ipl = VR_UNION_ITEMS_FIRST;
     if (cand) t.last_seq = t.seq;
-    t.ipl_of_seq[t.seq & 15u] = ipl;
-    if (tune_debug) std::fprintf(stderr, "[sweep tune] launch %u: %u items per lane, phase %d\n", t.seq, ipl, t.phase);
+    if (++c->tag == 0u) c->tag = 1u;
+    vr_ctx::Sent &rec = c->sent[c->tag & 15u];
+    rec.tag = c->tag; rec.local_seq = t.seq; rec.ipl = ipl; rec.slot = slot; rec.key = key;
+    if (tune_debug()) std::fprintf(stderr, "[sweep tune] workload %d launch %u: %u items per lane, phase %d\n", slot, t.seq, ipl, t.phase);
     *ipl_out = ipl;
-    *seq_out = t.seq;
+    *tag_out = c->tag;
 }
 
 /* the same view, field by field (the struct has padding; the fifteen floats at its start are compared as bit patterns) */
@@ -571,8 +611,7 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
     } else {
         if (!per_pixel) {
             /* growing the scratch is the only allocation on this path; it happens when a larger view comes */
-            const size_t need = ((vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count) + 255) & ~(size_t)255) +
-                                vr_pipeline_lpt_bytes(view->width, row_end - row_begin);
+            const size_t need = vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count);
             if (need > c->work_cap) VR_HIP(hipStreamSynchronize(s));
             rc = ensure(&c->d_work, &c->work_cap, need);
             if (rc != VR_OK) return rc;
@@ -600,103 +639,69 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
     static const uint32_t forced_ipl = std::getenv("VR_SWEEP_ITEMS") ? (uint32_t)std::atoi(std::getenv("VR_SWEEP_ITEMS")) : 0u; /* for tuning runs */
     if (forced_ipl) ipl = forced_ipl;
     else if ((sweep_kernel || union_kernel) && !fixed_scratch)
-        sweep_tune_next(c, view, iso_begin, iso_count, row_begin, row_end - row_begin, band_rows, union_kernel, &ipl, &seq);
-    /* tiles longest first when the last call in this workspace was this very call (see vr_ctx::LastUnion) */
+        sweep_tune_next(c, view, iso_count, row_end - row_begin, band_rows, union_kernel, &ipl, &seq);
+    /* tiles longest first when the context remembers this very call (see vr_ctx::LptEntry) */
     static const bool lpt_off = std::getenv("VR_UNION_LPT") && std::atoi(std::getenv("VR_UNION_LPT")) == 0; /* for A/B runs */
     int lpt_mode = 0;
-    if (!fixed_scratch && !per_pixel) {
-        vr_ctx::LastUnion &u = c->last_union;
-        if (union_kernel && !lpt_off) {
-            const bool same = u.have && u.tree_id == c->tree_id && u.work == work && same_view(u.view, k) &&
-                              u.iso_begin == iso_begin && u.iso_count == iso_count && u.row_begin == row_begin && u.row_end == row_end;
-            if (!same) { u.lengths_ipl = 0; u.order_ipl = 0; }
-            if (u.order_ipl == ipl) {
-                lpt_mode = VR_LPT_USE;
-            } else if (u.lengths_ipl == ipl) {
-                lpt_mode = VR_LPT_SORT | VR_LPT_USE;
-                u.order_ipl = ipl; u.lengths_ipl = 0;
-            } else if (u.lengths_ipl) { /* lengths of another cut: good enough to order by, and this cut's are kept */
-                lpt_mode = VR_LPT_SORT | VR_LPT_USE | VR_LPT_RECORD;
-                u.order_ipl = u.lengths_ipl; u.lengths_ipl = ipl;
-            } else if (u.order_ipl) {   /* an order from another cut, no lengths */
-                lpt_mode = VR_LPT_USE | VR_LPT_RECORD;
-                u.lengths_ipl = ipl;
-            } else {
-                static const bool chord_off = std::getenv("VR_UNION_CHORD") && std::atoi(std::getenv("VR_UNION_CHORD")) == 0; /* A/B runs */
-                lpt_mode = VR_LPT_RECORD | VR_LPT_CLEAR | (chord_off ? 0 : VR_LPT_CHORD | VR_LPT_USE);
-                u.lengths_ipl = ipl;
-            }
-            u.tree_id = c->tree_id; u.view = k;
-            u.iso_begin = iso_begin; u.iso_count = iso_count; u.row_begin = row_begin; u.row_end = row_end; u.work = work;
+    vr_ctx::LptEntry *lpt = nullptr;
+    if (!fixed_scratch && union_kernel && !lpt_off) {
+        int oldest = 0;
+        for (int i = 0; i < vr_ctx::kRemember; i++) {
+            vr_ctx::LptEntry &u = c->lpts[i];
+            if (u.have && u.tree_id == c->tree_id && same_view(u.view, k) && u.iso_begin == iso_begin && u.iso_count == iso_count &&
+                u.row_begin == row_begin && u.row_end == row_end)
+                lpt = &u;
+            if (u.used < c->lpts[oldest].used) oldest = i;
         }
+        if (!lpt) { /* a call the context does not remember: the oldest entry makes room (its buffer stays) */
+            lpt = &c->lpts[oldest];
+            lpt->have = false; lpt->lengths_ipl = 0; lpt->order_ipl = 0;
+        }
+        const size_t need = vr_pipeline_lpt_bytes(view->width, row_end - row_begin);
+        if (need > lpt->cap) {
+            VR_HIP(hipStreamSynchronize(s)); /* an earlier launch may still use the buffer */
+            rc = ensure(&lpt->mem, &lpt->cap, need);
+            if (rc != VR_OK) { lpt->have = false; return rc; }
+            lpt->have = false; lpt->lengths_ipl = 0; lpt->order_ipl = 0;
+        }
+        vr_ctx::LptEntry &u = *lpt;
+        if (u.have && u.order_ipl == ipl) {
+            lpt_mode = VR_LPT_USE;
+        } else if (u.have && u.lengths_ipl == ipl) {
+            lpt_mode = VR_LPT_SORT | VR_LPT_USE;
+            u.order_ipl = ipl; u.lengths_ipl = 0;
+        } else if (u.have && u.lengths_ipl) { /* lengths of another cut: good enough to order by, and this cut's are kept */
+            lpt_mode = VR_LPT_SORT | VR_LPT_USE | VR_LPT_RECORD;
+            u.order_ipl = u.lengths_ipl; u.lengths_ipl = ipl;
+        } else if (u.have && u.order_ipl) {   /* an order from another cut, no lengths */
+            lpt_mode = VR_LPT_USE | VR_LPT_RECORD;
+            u.lengths_ipl = ipl;
+        } else {                               /* a first call: the order comes from the rays' chords through the volume */
+            static const bool chord_off = std::getenv("VR_UNION_CHORD") && std::atoi(std::getenv("VR_UNION_CHORD")) == 0; /* A/B runs */
+            lpt_mode = VR_LPT_RECORD | VR_LPT_CLEAR | (chord_off ? 0 : VR_LPT_CHORD | VR_LPT_USE);
+            u.lengths_ipl = ipl; u.order_ipl = 0;
+        }
+        u.tree_id = c->tree_id; u.view = k;
+        u.iso_begin = iso_begin; u.iso_count = iso_count; u.row_begin = row_begin; u.row_end = row_end;
+        u.used = ++c->use_clock;
         u.have = false; /* until the launch is known to be enqueued */
     }
+    void *lpt_mem = lpt ? lpt->mem : nullptr;
     if (c->wide)
         VR_HIP(vr_launch_render_wide(variant, s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
-                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq, c->ranges_nested, lpt_mode));
+                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq, c->ranges_nested, lpt_mode, lpt_mem));
     else
         VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
                                 row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq,
-                                c->ranges_nested, lpt_mode));
-    if (lpt_mode) c->last_union.have = true;
-    if (lpt_mode && std::getenv("VR_LPT_DEBUG")) { /* the lengths this launch left, as a histogram */
-        (void)hipStreamSynchronize(s);
-        const size_t off = (vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count) + 255) & ~(size_t)255;
-        uint32_t n_tiles = 0;
-        (void)hipMemcpy(&n_tiles, (char *)work + off, 4, hipMemcpyDeviceToHost);
-        n_tiles = n_tiles < VR_LPT_MAX_TILES ? n_tiles : 0u;
-        std::vector<uint32_t> len(n_tiles);
-        if (n_tiles)
-            (void)hipMemcpy2D(len.data(), 4, (char *)work + off + 256, VR_LPT_STRIDE_WORDS * 4u, 4, n_tiles, hipMemcpyDeviceToHost);
-        uint32_t mx = 0; unsigned long long sum = 0;
-        for (uint32_t v : len) { mx = v > mx ? v : mx; sum += v; }
-        std::fprintf(stderr, "[lpt] mode %d tiles %u longest %u rounds mean %.1f;", lpt_mode, n_tiles, mx, n_tiles ? (double)sum / n_tiles : 0.0);
-        uint32_t h[16] = { 0 };
-        for (uint32_t v : len) h[mx ? (uint32_t)((uint64_t)v * 15u / mx) : 0u]++;
-        for (int i = 0; i < 16; i++) std::fprintf(stderr, " %u", h[i]);
-        std::fprintf(stderr, "\n");
-        if (std::getenv("VR_LPT_CHORD") && n_tiles && mx) { /* experiment: how well does the chord through the root box predict a tile's length? */
-            std::vector<float> rays(4 * (size_t)n_tiles * 64u, 0.0f);
-            (void)hipMemcpy(rays.data(), work, rays.size() * 4u, hipMemcpyDeviceToHost);
-            std::vector<float> chord(n_tiles, 0.0f);
-            const float o[3] = { k.ox, k.oy, k.oz }, dim[3] = { (float)k.rdx, (float)k.rdy, (float)k.rdz };
-            for (uint32_t t = 0; t < n_tiles; t++)
-                for (uint32_t l = 0; l < 64u; l++) {
-                    const float *r = &rays[4 * ((size_t)t * 64u + l)];
-                    float te = 1e30f;
-                    for (int a = 0; a < 3; a++) {
-                        if (r[a] > 1e-8f) te = std::fmin(te, (dim[a] - o[a]) / r[a]);
-                        else if (r[a] < -1e-8f) te = std::fmin(te, (0.0f - o[a]) / r[a]);
-                    }
-                    const float c = te - r[3];
-                    if (c > chord[t] && c < 1e6f) chord[t] = c;
-                }
-            auto ranks = [&](std::vector<double> v) { std::vector<uint32_t> idx(v.size()); for (uint32_t i = 0; i < v.size(); i++) idx[i] = i;
-                std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return v[a] < v[b]; });
-                std::vector<double> rk(v.size()); for (uint32_t i = 0; i < v.size(); i++) rk[idx[i]] = i; return rk; };
-            std::vector<double> a(n_tiles), b(n_tiles), pos(n_tiles);
-            for (uint32_t t = 0; t < n_tiles; t++) { a[t] = chord[t]; b[t] = len[t]; pos[t] = -(double)t; }
-            auto corr = [&](const std::vector<double> &x, const std::vector<double> &y) { double mx2 = 0, my = 0; for (size_t i = 0; i < x.size(); i++) { mx2 += x[i]; my += y[i]; }
-                mx2 /= x.size(); my /= y.size(); double sxy = 0, sxx = 0, syy = 0; for (size_t i = 0; i < x.size(); i++) { sxy += (x[i] - mx2) * (y[i] - my); sxx += (x[i] - mx2) * (x[i] - mx2); syy += (y[i] - my) * (y[i] - my); }
-                return sxy / std::sqrt(sxx * syy); };
-            std::fprintf(stderr, "[lpt] rank correlation with the lengths: chord %.3f, list position (earlier = longer) %.3f\n", corr(ranks(a), ranks(b)), corr(ranks(pos), ranks(b)));
-            /* where do the 5 %% longest tiles lie in either order? */
-            std::vector<uint32_t> by_len(n_tiles), by_chord(n_tiles);
-            for (uint32_t t = 0; t < n_tiles; t++) by_len[t] = by_chord[t] = t;
-            std::sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return len[x] > len[y]; });
-            std::sort(by_chord.begin(), by_chord.end(), [&](uint32_t x, uint32_t y) { return chord[x] > chord[y]; });
-            std::vector<uint32_t> chord_pos(n_tiles); for (uint32_t i = 0; i < n_tiles; i++) chord_pos[by_chord[i]] = i;
-            const uint32_t top = n_tiles / 20u; double mean_list = 0, mean_chord = 0; uint32_t worst_list = 0, worst_chord = 0;
-            for (uint32_t i = 0; i < top; i++) { const uint32_t t = by_len[i]; mean_list += t; mean_chord += chord_pos[t]; worst_list = t > worst_list ? t : worst_list; worst_chord = chord_pos[t] > worst_chord ? chord_pos[t] : worst_chord; }
-            std::fprintf(stderr, "[lpt] the %u longest tiles: mean / last position in list order %.0f / %u, in chord order %.0f / %u (of %u)\n", top, mean_list / top, worst_list, mean_chord / top, worst_chord, n_tiles);
-        }
-    }
+                                c->ranges_nested, lpt_mode, lpt_mem));
+    if (lpt) lpt->have = true;
     if (timing) c->ev_used += 2;
     if ((sweep_kernel || union_kernel) && !fixed_scratch) {
         c->info_off = vr_pipeline_info_offset(view->width, row_end - row_begin);
         c->last_ipl = ipl;
-        c->order_flag_off = (lpt_mode & VR_LPT_USE) ? ((vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count) + 255) & ~(size_t)255) + 4u : 0u;
-        if (c->tune.phase != 2 && !forced_ipl) /* the report follows the launch on its stream; the next launch reads it if it has arrived */
+        c->order_flag = (lpt_mode & VR_LPT_USE) && lpt_mem ? (const char *)lpt_mem + 4u : nullptr;
+        const bool settled = forced_ipl || (c->cur_tune >= 0 && c->tunes[c->cur_tune].t.phase == 2);
+        if (!settled) /* the report follows the launch on its stream; a later launch reads it if it has arrived */
             VR_HIP(hipMemcpyAsync(c->h_info, (const char *)c->d_work + c->info_off, 48, hipMemcpyDeviceToHost, s));
     }
     return VR_OK;
@@ -991,13 +996,13 @@ int vr_sweep_info_read(vr_ctx *c, vr_sweep_info *out)
     out->rendered_again = runs_redo[1] ? 1u : 0u;
     out->reserved = 0u;
     out->tiles_longest_first = 0;
-    if (c->order_flag_off) { /* 1 = ordered by item lengths; 2 (a first call's order by chords) is not reported as that */
+    if (c->order_flag) { /* 1 = ordered by item lengths; 2 (a first call's order by chords) is not reported as that */
         uint32_t made_from = 0;
-        VR_HIP(hipMemcpy(&made_from, (const char *)c->d_work + c->order_flag_off, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        VR_HIP(hipMemcpy(&made_from, c->order_flag, sizeof(uint32_t), hipMemcpyDeviceToHost));
         out->tiles_longest_first = made_from == 1u ? 1u : 0u;
     }
     out->items_per_lane = c->last_ipl;
-    out->cut_settled = c->tune.phase == 2 ? 1u : 0u;
+    out->cut_settled = c->cur_tune >= 0 && c->tunes[c->cur_tune].t.phase == 2 ? 1u : 0u;
     return VR_OK;
 }
 

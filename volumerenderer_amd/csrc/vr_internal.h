@@ -34,10 +34,10 @@ enum {
  * lane of the grid: more blocks balance better, and every block re-walks its first traversal.  launch_seq tags the
  * launch in the kernel's report (0 = untagged). */
 #define VR_SWEEP_ITEMS_DEFAULT 8u
-/* (ray, iso block) items per lane of the grid that the union kernel starts from for long sweeps (tuned per workload) */
-#define VR_UNION_ITEMS_DEFAULT 4u
-/* ... and what the first launch of a workload runs with (the tiles of a first call are in list order: fewer, longer items) */
-#define VR_UNION_ITEMS_FIRST 3u
+/* (ray, iso block) items per lane of the grid that the union kernel starts from for long sweeps (tuned per workload); it is what
+ * a workload's first launch runs with, whose tiles are not yet in the order of their lengths: fewer, longer items do better
+ * there (Skull, first call: 1.40 ms with 2 or 3 items per lane, 1.56 with 4, 1.75 with 6) */
+#define VR_UNION_ITEMS_DEFAULT 3u
 /* iso values per call from which the default is the kernel with one traversal per ray for all of them */
 #define VR_UNION_MIN_ISOS 8u
 /* runs of iso values that may leave the union walks of one call and be finished one iso value at a time (a few per thousand
@@ -52,9 +52,10 @@ extern "C" int vr_host_check_kdt_wide_nested(const uint32_t *nodes, uint64_t n_s
 /* Device scratch the pipeline variant needs for one call (ray list, tile offsets, queue heads). */
 size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso_count);
 
-/* Behind the pipeline workspace of a call (rounded up to 256 bytes): what the kernel with one traversal per ray keeps from
- * launch to launch of the same call -- per tile of 64 rays the length of its longest item, and the order of the tiles made
- * from it (longest first).  lpt_mode of the launchers is 0 (the arrays are not there: nothing kept, list order) or a sum of: */
+/* What the kernel with one traversal per ray keeps from launch to launch of the same call, in a device buffer of its own
+ * (lpt_mem of the launchers, vr_pipeline_lpt_bytes long; the context holds one per call it remembers): per tile of 64 rays the
+ * length of its longest item, and the order of the tiles made from it (longest first).  lpt_mode of the launchers is 0 (nothing
+ * kept, list order; always so without a buffer) or a sum of: */
 enum {
     VR_LPT_RECORD = 1, /* the launch keeps the lengths of its items (they start from what is there: zero after a sort or a clear) */
     VR_LPT_SORT = 2,   /* the lengths of an earlier launch of this very call are in place: the pre-pass makes the order from them
@@ -78,7 +79,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                             const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
                             const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end,
-                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested, int lpt_mode);
+                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested, int lpt_mode, void *lpt_mem);
 
 /* Once per device, with that device current (vr_ctx_create calls it; safe from several threads): raises the
  * dynamic-LDS ceiling of the persistent kernels, which is a property of the function on the device, and looks
@@ -114,7 +115,7 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
                                  uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
                                  hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq,
-                                 bool ranges_nested, int lpt_mode);
+                                 bool ranges_nested, int lpt_mode, void *lpt_mem);
 
 
 /* One ray with the literal loop, every iteration recorded (vr_refine.hip): d_steps holds cap records, d_report one. */

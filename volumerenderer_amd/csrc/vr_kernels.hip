@@ -2335,23 +2335,24 @@ size_t vr_pipeline_lpt_bytes(uint32_t width, uint32_t n_rows)
     return 256u + n * VR_LPT_STRIDE_WORDS * sizeof(uint32_t) + ((n * sizeof(uint32_t) + 255) & ~(size_t)255); /* header, lengths, order */
 }
 
-/* the tile lengths and the tile order of the union kernel lie behind the pipeline workspace of the call */
-static void lpt_arrays(void *workspace, uint32_t width, uint32_t n_rows, uint32_t iso_count, uint32_t **cost, uint32_t **order)
+/* the tile lengths and the tile order of the union kernel lie in a buffer of their own (vr_pipeline_lpt_bytes long), one per
+ * call that the context remembers: [256-byte header][lengths, one 256-byte line per tile][order] */
+static void lpt_arrays(void *lpt_mem, uint32_t width, uint32_t n_rows, uint32_t **cost, uint32_t **order)
 {
-    char *w = (char *)workspace + ((vr_pipeline_workspace_bytes(width, n_rows, iso_count) + 255) & ~(size_t)255);
+    char *w = (char *)lpt_mem;
     *cost = (uint32_t *)(w + 256u);
     *order = (uint32_t *)(w + 256u + lpt_tiles(width, n_rows) * VR_LPT_STRIDE_WORDS * sizeof(uint32_t));
 }
 
 /* For a union launch, from the bits of lpt_mode (vr_internal.h): where the lengths and the order lie, whether the pre-pass
  * sorts (*sort_into), whether the kernel follows the order (*order) and keeps lengths (*keep); clears the lengths when asked. */
-static hipError_t lpt_prepare(hipStream_t stream, int lpt_mode, void *workspace, const VrViewK &view, uint32_t n_rows, uint32_t iso_count,
+static hipError_t lpt_prepare(hipStream_t stream, int lpt_mode, void *lpt_mem, const VrViewK &view, uint32_t n_rows,
                               uint32_t **order, uint32_t **sort_into, uint32_t **chord_into, uint32_t **cost, uint32_t *keep)
 {
     *order = nullptr; *sort_into = nullptr; *chord_into = nullptr; *cost = nullptr; *keep = 0u;
-    if (lpt_mode == 0) return hipSuccess;
+    if (lpt_mode == 0 || !lpt_mem) return hipSuccess;
     uint32_t *o;
-    lpt_arrays(workspace, view.width, n_rows, iso_count, cost, &o);
+    lpt_arrays(lpt_mem, view.width, n_rows, cost, &o);
     if (lpt_mode & VR_LPT_USE) *order = o;
     if (lpt_mode & VR_LPT_SORT) *sort_into = o;
     if (lpt_mode & VR_LPT_CHORD) *chord_into = o;
@@ -2399,7 +2400,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                             const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
                             const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end,
-                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested, int lpt_mode)
+                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested, int lpt_mode, void *lpt_mem)
 {
     const uint32_t n_rows = row_end - row_begin;
     const uint32_t stack_levels = max_depth > 0 ? max_depth : 1u;
@@ -2451,7 +2452,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     const bool use_union = sweep && variant != VR_KERNEL_SWEEP && !any_tap && ranges_nested;
     Prepass pp;
     uint32_t *tile_order = nullptr, *sort_into = nullptr, *chord_into = nullptr, *tile_cost = nullptr, keep_lengths = 0;
-    if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, &tile_order, &sort_into, &chord_into, &tile_cost, &keep_lengths)) != hipSuccess)
+    if (use_union && (e = lpt_prepare(stream, lpt_mode, lpt_mem, view, n_rows, &tile_order, &sort_into, &chord_into, &tile_cost, &keep_lengths)) != hipSuccess)
         return e;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
                             VR_FLAG_OOB << 24, workspace, pp, tile_cost, sort_into, (uint32_t)n_cus * kTraceBlocksPerCu * kTraceThreads, chord_into)) != hipSuccess)
@@ -2653,7 +2654,7 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
                                  uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
                                  hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq,
-                                 bool ranges_nested, int lpt_mode)
+                                 bool ranges_nested, int lpt_mode, void *lpt_mem)
 {
     const uint32_t n_rows = row_end - row_begin;
     hipError_t e = hipSuccess;
@@ -2673,7 +2674,7 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
     const bool use_union = sweep && variant != VR_KERNEL_SWEEP && !any_tap && ranges_nested;
     uint32_t *tile_order = nullptr, *sort_into = nullptr, *chord_into = nullptr, *tile_cost = nullptr, keep_lengths = 0;
-    if (use_union && (e = lpt_prepare(stream, lpt_mode, workspace, view, n_rows, iso_count, &tile_order, &sort_into, &chord_into, &tile_cost, &keep_lengths)) != hipSuccess)
+    if (use_union && (e = lpt_prepare(stream, lpt_mode, lpt_mem, view, n_rows, &tile_order, &sort_into, &chord_into, &tile_cost, &keep_lengths)) != hipSuccess)
         return e;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
                             VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp, tile_cost, sort_into,

@@ -60,45 +60,85 @@ def band_rows_of(rank, world, height, band_rows=BAND_ROWS):
     return rows
 
 
+class FrameGather:
+    """The one exchange step of a sharded render: every rank's part of the framebuffers goes to rank `dst`, point to point
+    (grouped isend / irecv: ncclSend / ncclRecv under the "nccl" backend, no ring -- rank dst's ingress links are the bound).
+    Built once per job; calling it gathers one step's parts and allocates nothing:
+
+      frames   parts[r] = counts[r] leading entries (iso shards: whole frames): received straight into their place in the
+               result, no staging, no copy besides rank dst's own part
+      rows     parts[r] = [iso, len(row_lists[r]), W, 3] with the image rows row_lists[r] (contiguous blocks or bands): a part
+               is contiguous on the wire but strided in the result, so it is received into a staging buffer of its own and
+               put in place by one indexed copy -- one pass over the framebuffer in all
+
+    The result lives in the object ([sum(counts), ...] or [iso, height, W, 3]) and is overwritten by the next call."""
+
+    def __init__(self, like, counts=None, row_lists=None, height=None, dst=0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch = dist, torch
+        self.dst, self.group = dst, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rows = row_lists is not None
+        tail = tuple(like.shape[1:]) if not self.rows else None
+        self.out, self.staging, self.index = None, {}, {}
+        if self.rows:
+            self.counts = [len(r) for r in row_lists]
+            if self.rank == dst:
+                n_iso = like.shape[0]
+                self.out = torch.empty((n_iso, height) + tuple(like.shape[2:]), dtype=like.dtype, device=like.device)
+                for r in range(self.world):
+                    if self.counts[r] == 0:
+                        continue
+                    self.index[r] = torch.tensor(row_lists[r], dtype=torch.long, device=like.device)
+                    if r != dst:
+                        self.staging[r] = torch.empty((n_iso, self.counts[r]) + tuple(like.shape[2:]), dtype=like.dtype, device=like.device)
+        else:
+            self.counts = [int(c) for c in counts]
+            if self.rank == dst:
+                self.out = torch.empty((sum(self.counts),) + tail, dtype=like.dtype, device=like.device)
+
+    def __call__(self, local):
+        dist = self.dist
+        if self.world == 1:
+            return local
+        if self.rank != self.dst:
+            if self.counts[self.rank] > 0:
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), self.dst, self.group)]):
+                    req.wait()
+            return None
+        ops, off = [], 0
+        for r in range(self.world):
+            n = self.counts[r]
+            if n and r != self.dst:
+                into = self.staging[r] if self.rows else self.out[off:off + n]
+                ops.append(dist.P2POp(dist.irecv, into, r, self.group))
+            off += n
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        # rank dst's own part goes in place while the others are on the wire
+        if self.counts[self.dst]:
+            if self.rows:
+                self.out.index_copy_(1, self.index[self.dst], local)
+            else:
+                own = sum(self.counts[:self.dst])
+                self.out[own:own + self.counts[self.dst]].copy_(local)
+        for req in reqs:
+            req.wait()
+        if self.rows:
+            for r, part in self.staging.items():
+                self.out.index_copy_(1, self.index[r], part)
+        return self.out
+
+
 def gather_rows(local, row_lists, height, dst=0, group=None):
     """Gathers per-rank frames [iso, rows_r, W, 3] whose rows are row_lists[r] of the image (contiguous blocks or
-    bands) to rank `dst` and puts every row in its place: returns [iso, height, W, 3] on `dst`, None elsewhere."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    counts = [len(r) for r in row_lists]
-    rows_first = local.transpose(0, 1).contiguous()  # [rows_r, iso, W, 3]: the gathered dimension leads
-    got = gather_frames(rows_first, counts, dst=dst, group=group) if world > 1 else rows_first
-    if rank != dst:
-        return None
-    order = torch.tensor([r for rows in row_lists for r in rows], dtype=torch.long, device=got.device)
-    full = torch.empty((height,) + tuple(got.shape[1:]), dtype=got.dtype, device=got.device)
-    full[order] = got
-    return full.transpose(0, 1).contiguous()
+    bands) to rank `dst` and puts every row in its place: returns [iso, height, W, 3] on `dst`, None elsewhere.
+    One-shot form of FrameGather (which a job that gathers every step builds once)."""
+    return FrameGather(local, row_lists=row_lists, height=height, dst=dst, group=group)(local)
 
 
 def gather_frames(local, counts, dst=0, group=None):
-    """Gathers per-rank tensors whose leading dimension differs (counts[r] entries on rank r) to rank
-    `dst` and concatenates them along dim 0.  Returns the full tensor on `dst`, None elsewhere.
-    Uses point-to-point gather (no ring): rank dst's ingress links are the bound."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if world == 1:
-        return local
-    maxc = max(counts)
-    pad_shape = (maxc,) + tuple(local.shape[1:])
-    buf = local
-    if local.shape[0] != maxc:
-        buf = torch.zeros(pad_shape, dtype=local.dtype, device=local.device)
-        buf[: local.shape[0]] = local
-    if rank == dst:
-        parts = [torch.empty(pad_shape, dtype=local.dtype, device=local.device) for _ in range(world)]
-        dist.gather(buf, gather_list=parts, dst=dst, group=group)
-        return torch.cat([parts[r][: counts[r]] for r in range(world)], dim=0)
-    dist.gather(buf, gather_list=None, dst=dst, group=group)
-    return None
+    """Gathers per-rank tensors whose leading dimension differs (counts[r] entries on rank r) to rank `dst`, one behind
+    the other along dim 0.  Returns the full tensor on `dst`, None elsewhere.  One-shot form of FrameGather."""
+    return FrameGather(local, counts=counts, dst=dst, group=group)(local)
