@@ -299,7 +299,10 @@ int vr_refine_device(vr_ctx *ctx, const vr_view *view, uint32_t n_frames, uint32
 /* ---- one ray, step by step ------------------------------------------------------------------ */
 
 /* The reference's per-ray debug print (traceRay compiled with dbp = true, src/raytrace.zig:133-146, 164-198) as
- * data: one record per iteration of its loop, in order. */
+ * data: one record per iteration of its loop, in order.  Not covered: what the reference prints inside a MOVE whose point is
+ * still inside the box it left ("VOLUME NOT ESQd!!!" with the node box, "previous node not escaped!", "!escape help needed!",
+ * src/raytrace.zig:207-240) -- there is no record field for it, so the trace of a ray with escape helps
+ * (vr_render_stats.escape_help_events counts them; 0 on every volume tried) lacks those lines. */
 #define VR_STEP_ZOOM 0u /* "ZOOM!" :189-192 */
 #define VR_STEP_HIT 1u  /* "HIT!"  :179-187 */
 #define VR_STEP_MOVE 2u /* "MOVE!" :197-205 */

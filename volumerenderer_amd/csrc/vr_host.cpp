@@ -499,7 +499,7 @@ void vr_free(void *p) { std::free(p); }
 } // extern "C"
 
 /* The layout of the reference's per-ray debug print (traceRay with dbp = true, src/raytrace.zig:133-146, 149-154,
- * 164-198). */
+ * 164-198); the lines it prints inside a MOVE that needs escape help (:207-240) are not reproduced. */
 extern "C" int vr_print_ray_trace(const vr_ray_report *r, const vr_ray_step *steps, const char *path)
 {
     if (!r || (r->n_stored && !steps)) return VR_EARG;
