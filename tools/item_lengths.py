@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box, measuring build (tools/tune_build.sh items -DVR_MEASURE_ITEMS -DVR_SWEEP_MAX_BLOCKS=256): how long is every
+"""GPU box, measuring build (tools/tune_build.sh items -DVR_MEASURE -DVR_SWEEP_MAX_BLOCKS=256): how long is every
 (ray, block of iso values) item of the union kernel, for several cuts of the iso range down to one iso value per item?
 
     VR_LIB_PATH=volumerenderer_amd/tune/libvr_items.so python tools/item_lengths.py [volume] [out.txt]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box, measuring build (tools/tune_build.sh items -DVR_MEASURE_ITEMS -DVR_SWEEP_MAX_BLOCKS=256): the rounds of ONE
+"""GPU box, measuring build (tools/tune_build.sh items -DVR_MEASURE -DVR_SWEEP_MAX_BLOCKS=256): the rounds of ONE
 (ray, block) item of the union kernel's Skull sweep, one line per round: round, us since the launch began, lanes of its wave
 holding a front, lanes descending, whether the traced lane is popping.
 usage: VR_LIB_PATH=.../libvr_items.so VR_SWEEP_ITEMS=3 python tools/item_trace.py ray block blocks_per_ray out.txt"""

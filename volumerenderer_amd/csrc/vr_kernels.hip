@@ -30,11 +30,7 @@
 #include <mutex>
 #include <vector>
 
-#ifdef VR_MEASURE_ITEMS /* measuring build: how often a wave runs through each piece of the union kernel's lane code */
-__device__ unsigned long long g_wave_counts[24];
-#define VR_WC(i) do { const unsigned long long e__ = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)e__) - 1u) atomicAdd(&g_wave_counts[i], 1ull); } while (0)
-#endif
-
+#include "vr_measure.h" /* empty macros unless -DVR_MEASURE */
 #include "vr_internal.h"
 #include "vr_trace_wide.h"
 #include "vr_trace_union.h"
@@ -534,27 +530,6 @@ __global__ void vr_k_tap_defaults(VrTapsK taps, uint64_t n, uint32_t oob_word)
 
 /* --------------------------------------------------------- pipeline: persistent trace ---- */
 
-#ifdef VR_DIAG /* diagnostic build only: where a wave's cycles go (never compiled into the product library) */
-__device__ unsigned long long g_diag[20];
-__device__ unsigned long long g_wave_span[3 * 8192]; /* per wave: begin, queue empty, end (s_memrealtime) */
-__device__ unsigned long long g_union_hist[3 * 128]; /* vr_k_union, per 20 us of the launch: alive lanes, sampled rounds, waves that ended */
-#define DIAG_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define DIAG_ADD(i, val) d_acc[i] += (unsigned long long)(val)
-#else
-#define DIAG_T(var)
-#define DIAG_ADD(i, val)
-#endif
-
-#ifdef VR_MEASURE_ITEMS /* measuring build only: the length of every (ray, block of iso values) item of a union launch */
-constexpr uint32_t kMeasureItemsCap = 80u << 20;
-__device__ uint32_t g_item_rounds[kMeasureItemsCap]; /* [ray * n_blocks + block]: rounds from the item's start to the end of its last front */
-__device__ uint32_t g_item_ticks[kMeasureItemsCap];  /* the same in ticks of the 100 MHz clock */
-__device__ uint32_t g_item_begin[kMeasureItemsCap];  /* when the item started, in ticks from the launch's first wave (+ 1) */
-__device__ uint32_t g_item_dims[4];                  /* rays in the list, blocks per ray, iso values per block, first iso value */
-__device__ uint32_t g_trace_slot = 0xffffffffu;      /* the item whose rounds are traced one by one (set by the host from VR_MEASURE_TRACE=ray,block) */
-__device__ uint32_t g_trace_n;
-__device__ uint32_t g_trace[2 * 4096];               /* per round of that item: tick since the launch began, lanes of its wave that hold a front | lanes descending << 8 | lanes popping << 16 */
-#endif
 
 #ifndef VR_TRACE_THREADS
 #define VR_TRACE_THREADS 1024
@@ -711,11 +686,6 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
      * run out of work on a cheap iso value move on to help with the expensive ones */
     const uint32_t k0 = (uint32_t)(((uint64_t)gw * iso_count) / n_waves);
     const uint32_t chunk_rays = trace_chunk(n_active, n_waves);
-#ifdef VR_DIAG
-    unsigned long long d_acc[20] = { 0 };
-    unsigned long long d_refills = 0;
-    DIAG_T(d_begin);
-#endif
 
     for (uint32_t visit = 0; visit < iso_count; visit++) {
         uint32_t k = k0 + visit;
@@ -732,7 +702,6 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
         uint32_t a_hit = 0, a_miss = 0, a_moves = 0, a_esc = 0, a_err = 0;
 
         for (;;) {
-            DIAG_T(d_t0);
             /* ---- refill idle lanes from this iso value's queue ---- */
             const unsigned long long idle = __ballot(!alive);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -748,41 +717,19 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
                     popping = false;
                 }
                 exhausted = chunk.exhausted();
-#ifdef VR_DIAG
-                d_refills++;
-#endif
             }
             if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
-            DIAG_T(d_t1);
-            DIAG_ADD(0, d_t1 - d_t0);
-            DIAG_ADD(5, 1);
-            DIAG_ADD(10, __popcll(__ballot(alive)));
-#ifdef VR_DIAG
-            uint32_t d_trips = 0, d_pops = 0, d_lanes_d = 0, d_lanes_m = 0, d_lanes_p = 0;
-            unsigned long long d_ta = 0, d_tb = 0;
-#endif
 
             if (alive) {
                 uint32_t go = VR_GO_MORE;
                 if (!popping) {
                     /* ---- descend while the node's density range holds the iso value (bounded) ---- */
-#ifdef VR_DIAG
-                    d_trips = stack.depth();
-#endif
 #ifdef VR_TRACE_NO_AHEAD
                     go = vr_lane_descend(L, iso, fetch, stack, kDescendTrips);
 #else
                     { VrNoIsoTrack none; go = vr_lane_descend_ahead(L, iso, fetch, stack, kDescendTrips, none); }
 #endif
-#ifdef VR_DIAG
-                    d_trips = stack.depth() - d_trips + (go != VR_GO_MORE ? 1u : 0u);
-#endif
                 }
-#ifdef VR_DIAG
-                d_lanes_d = popping ? 0u : 1u;
-                d_lanes_m = go == VR_GO_EXCLUDED ? 1u : 0u;
-                d_ta = __builtin_amdgcn_s_memtime();
-#endif
                 if (go == VR_GO_HIT) { /* shade and store (src/raytrace.zig:56-61) */
                     const uint8_t g = vr_shade(L.t);
                     frame[(uint64_t)pix * 3u + 0u] = g;
@@ -809,19 +756,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
                         }
                     }
                 }
-#ifdef VR_DIAG
-                d_tb = __builtin_amdgcn_s_memtime();
-#endif
                 if (alive && popping) {
                     /* ---- pop to the lowest ancestor that holds the new point (bounded) ---- */
-#ifdef VR_DIAG
-                    d_pops = stack.depth();
-                    d_lanes_p = 1;
-#endif
                     popping = !vr_lane_pop(L, stack, kPopTrips);
-#ifdef VR_DIAG
-                    d_pops = d_pops + (popping ? 0u : 1u) - stack.depth();
-#endif
                 }
                 if (!alive) {
                     a_checked += L.checked;
@@ -831,37 +768,11 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
                     }
                 }
             }
-#ifdef VR_DIAG
-            {
-                DIAG_T(d_t3);
-                DIAG_ADD(1, d_t3 - d_t1); /* everything after the refill */
-                const uint32_t m1 = wave_max(d_trips), s1 = wave_sum(d_trips), m2 = wave_max(d_pops), s2 = wave_sum(d_pops);
-                DIAG_ADD(6, m1); DIAG_ADD(7, s1); DIAG_ADD(8, m2); DIAG_ADD(9, s2);
-                DIAG_ADD(2, wave_sum(d_lanes_d)); DIAG_ADD(3, wave_sum(d_lanes_m)); DIAG_ADD(4, wave_sum(d_lanes_p));
-                DIAG_ADD(14, wave_max(d_lanes_m));
-                {
-                    /* phase boundaries as seen by the first lane that ran the phases */
-                    const unsigned long long ta = __shfl(d_ta, __ffsll(__ballot(d_ta != 0)) - 1, 64);
-                    const unsigned long long tb = __shfl(d_tb, __ffsll(__ballot(d_tb != 0)) - 1, 64);
-                    if (ta && tb) { DIAG_ADD(15, ta - d_t1); d_acc[13] += tb - ta; d_acc[12] += d_t3 - tb; }
-                }
-            }
-#endif
         }
 
         /* ---- per-iso counters ---- */
         if (stats) wave_stats_out(stats, slots, k, gw, n_waves, lane, a_checked, a_hit, a_miss, a_esc, a_moves, a_err);
     }
-#ifdef VR_DIAG
-    {
-        DIAG_T(d_end);
-        d_acc[11] = d_end - d_begin;
-        d_acc[16] = 1;
-        d_acc[17] = d_refills;
-        if (lane == 0)
-            for (int i = 0; i < 20; i++) atomicAdd(&g_diag[i], d_acc[i]);
-    }
-#endif
 }
 
 /* --------------------------------------------------------- pipeline: iso sweep kernel ---- */
@@ -1062,12 +973,6 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
     const uint32_t n_items = ((n_active + 63u) & ~63u) * n_blocks; /* more than one block only while n_active is far below 2^32 / 64 */
     const uint64_t frame_bytes = frame_pixels * 3u;
 
-#ifdef VR_DIAG
-    unsigned long long d_acc[20] = { 0 };
-    const unsigned long long d_begin = __builtin_amdgcn_s_memtime(), d_rbegin = __builtin_amdgcn_s_memrealtime();
-    unsigned long long d_exh = 0, d_rexh = 0;
-    uint32_t d_lane_traces = 0, d_lane_emit = 0;
-#endif
     /* the kernel's report on itself (read back with vr_sweep_info_read): traversals done, and the 100 MHz ticks at
      * which the first wave started, the first wave found the queue empty, and the last wave ended */
     unsigned long long *info = (unsigned long long *)(n_active_ptr + 16);
@@ -1113,9 +1018,6 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
             }
             exhausted = chunk.exhausted();
             if (exhausted && !tick_empty) tick_empty = __builtin_amdgcn_s_memrealtime();
-#ifdef VR_DIAG
-            if (exhausted && !d_exh) { d_exh = __builtin_amdgcn_s_memtime(); d_rexh = __builtin_amdgcn_s_memrealtime(); }
-#endif
         }
         if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
         /* ---- queue empty: idle lanes take over the upper half of the longest iso range left in the wave ---- */
@@ -1135,9 +1037,6 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 const uint32_t s_iso = (uint32_t)__builtin_amdgcn_readlane((int)iso, victim);
                 const uint32_t s_last = (uint32_t)__builtin_amdgcn_readlane((int)iso_last, victim);
                 const uint32_t mid = s_iso + ((s_last - s_iso) >> 1); /* the victim keeps [iso, mid] */
-#ifdef VR_DIAG
-                d_acc[9] += 1;
-#endif
                 if (lane == victim) iso_last = mid;
                 OPS::adopt(L, victim, lane == thief);
                 if (lane == thief) {
@@ -1154,26 +1053,13 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 }
             }
         }
-#ifdef VR_DIAG
-        d_acc[4] += 1; d_acc[5] += __popcll(__ballot(alive));
-        if (exhausted) { d_acc[10] += 1; d_acc[11] += __popcll(__ballot(alive)); }
-#endif
 
-#ifdef VR_DIAG
-        const unsigned long long d_p0 = __builtin_amdgcn_s_memtime();
-        unsigned long long d_p1 = d_p0, d_p2 = d_p0, d_p3 = d_p0;
-        d_acc[2] += __popcll(__ballot(alive && !popping));
-#endif
         if (alive) {
             uint32_t go = VR_GO_MORE;
             /* ---- descend while the node's density range holds the iso value (bounded) ---- */
             if (!popping) go = OPS::descend(L, v, iso, fetch, stack, track);
             bool done = false, hit = false;
             uint32_t err = 0;
-#ifdef VR_DIAG
-            d_p1 = __builtin_amdgcn_s_memtime();
-            d_acc[7] += __popcll(__ballot(go == VR_GO_EXCLUDED));
-#endif
             if (VR_SWEEP_KEEP && go != VR_GO_MORE && track.upper < seg_upper) {
                 /* `upper` went down since the last return to the root: the state at that return is the newest one
                  * the next walk shares (t, cell, moves and esc have not changed since) */
@@ -1191,26 +1077,14 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 if (L.checked > VR_MAX_CHECKED) { in_root = false; err = 1; }
                 if (in_root) popping = true; else done = true; /* left the volume: a miss (src/raytrace.zig:66-68) */
             }
-#ifdef VR_DIAG
-            d_p2 = __builtin_amdgcn_s_memtime();
-            d_acc[12] += __popcll(__ballot(popping && !done));
-#endif
             /* ---- pop to the lowest ancestor that holds the new point (bounded) ---- */
             if (popping && !done) popping = !OPS::pop(L, stack);
-#ifdef VR_DIAG
-            d_p3 = __builtin_amdgcn_s_memtime();
-            d_acc[13] += __popcll(__ballot(done));
-            d_acc[18] += __ballot(done) ? 1 : 0;
-#endif
 
             if (done) {
                 n_walks++;
                 /* ---- the traversal stands for every iso value from `iso` to `e` ---- */
                 const uint32_t e = track.upper < iso_last ? track.upper : iso_last;
                 const uint32_t k0 = iso - iso_begin, k1 = e + 1u - iso_begin;
-#ifdef VR_DIAG
-                d_lane_traces += 1; d_lane_emit += hit ? k1 - k0 : 0u;
-#endif
                 atomicAdd(&s_checks[k0], (unsigned long long)L.checked);
                 atomicAdd(&s_checks[k1], 0ull - (unsigned long long)L.checked);
                 uint32_t *c = s_cnt + (hit ? 0u : n_k);
@@ -1250,32 +1124,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                 }
             }
         }
-#ifdef VR_DIAG
-        {
-            const unsigned long long d_p4 = __builtin_amdgcn_s_memtime();
-            d_acc[14] += d_p1 - d_p0; d_acc[15] += d_p2 - d_p1; d_acc[16] += d_p3 - d_p2; d_acc[17] += d_p4 - d_p3;
-        }
-#endif
     }
 
-#ifdef VR_DIAG
-    {
-        const unsigned long long d_end = __builtin_amdgcn_s_memtime();
-        d_acc[6] = wave_sum(d_lane_traces); d_acc[8] = wave_sum(d_lane_emit);
-        {
-            const uint32_t gwv = blockIdx.x * (kTraceThreads / 64u) + (threadIdx.x >> 6);
-            const unsigned long long d_rend = __builtin_amdgcn_s_memrealtime();
-            if (lane == 0 && gwv < 8192u) { g_wave_span[3 * gwv] = d_rbegin; g_wave_span[3 * gwv + 1] = d_rexh ? d_rexh : d_rend; g_wave_span[3 * gwv + 2] = d_rend; }
-        }
-        d_acc[0] = (d_exh ? d_exh : d_end) - d_begin;
-        d_acc[1] = d_end - d_begin;
-        d_acc[3] = 1;
-        if (lane == 0) {
-            for (int i = 0; i < 20; i++) atomicAdd(&g_diag[i], d_acc[i]);
-            atomicMax(&g_diag[19], d_end - d_begin);
-        }
-    }
-#endif
     {
         const uint32_t w_walks = wave_sum(n_walks);
         if (lane == 0) {
@@ -1390,24 +1240,9 @@ struct UnionSink {
      * MOVEs each, spread over the 256 blocks of the grid, stay below. */
     __device__ __forceinline__ void park(uint32_t r0, uint32_t r1, uint32_t n_checks)
     {
-#ifdef VR_X_NO_PARKS /* experiment: what do the adds of the parked sets cost? (wrong counters) */
-        return;
-#endif
         const unsigned long long both = (unsigned long long)n_checks + (1ull << kParkMoveShift);
-#if defined(VR_X_PARK_U32)      /* experiments on what the parked sets' adds cost (wrong counters) */
-        atomicAdd((uint32_t *)&s_checks[r0 - iso_begin], n_checks);
-        atomicAdd((uint32_t *)&s_checks[r1 + 1u - iso_begin], 0u - n_checks);
-#elif defined(VR_X_PARK_FIRST)
-        atomicAdd(&s_checks[r0 - iso_begin], both);
-#elif defined(VR_X_PARK_SECOND)
-        atomicAdd(&s_checks[r1 + 1u - iso_begin], 0ull - both);
-#elif defined(VR_X_PARK_WRITE)
-        s_checks[r0 - iso_begin] = both;
-        s_checks[r1 + 1u - iso_begin] = 0ull - both;
-#else
         atomicAdd(&s_checks[r0 - iso_begin], both);
         atomicAdd(&s_checks[r1 + 1u - iso_begin], 0ull - both);
-#endif
     }
     __device__ __forceinline__ void hit(uint32_t r0, uint32_t r1, uint32_t n_checks, float t, uint32_t, uint32_t)
     {
@@ -1415,14 +1250,8 @@ struct UnionSink {
         add(0u, r0, r1, 1u);
         const uint8_t g = vr_shade(t); /* shade and store (src/raytrace.zig:56-61), one frame per iso value */
         uint8_t *p = rgb + (uint64_t)(r0 - iso_begin) * frame_bytes + (uint64_t)pix * 3u;
-#ifdef VR_X_NO_STORES /* experiment: what do the pixel stores cost? (wrong frames) */
-        if (frame_bytes == 1u) p[0] = g;
-#elif defined(VR_X_ONE_STORE) /* experiment: one store per run instead of one pixel per iso value (wrong frames) */
-        p[0] = g;
-#else
         VR_WC(16);
         for (uint32_t k = r0; k <= r1; k++, p += frame_bytes) { VR_WC(6); p[0] = g; p[1] = g; p[2] = g; }
-#endif
     }
     __device__ __forceinline__ void miss(uint32_t r0, uint32_t r1) { add(1u, r0, r1, 1u); }
     __device__ __forceinline__ void esc(uint32_t r0, uint32_t r1, uint32_t n) { add(3u, r0, r1, n); }
@@ -1530,6 +1359,24 @@ struct UnionWide {
     __device__ static __forceinline__ void after_pop(ULane &U, const Fetch &f) { vr_uw_after_pop(U, f); }
 };
 
+/* The front of a lane is finished: on with the iso values it has kept, if any (a front of their own from their own state),
+ * else the lane is idle and the item's length goes to its tile.  Returns what becomes of the lane's `alive` flag; `popping`
+ * is cleared by the caller when the lane goes on (the flags are passed and returned by value: taken by reference they ended
+ * up in scratch memory). */
+template <class UOPS, class Store, class Done>
+__device__ __forceinline__ bool union_front_done(typename UOPS::ULane &U, Store &stack, Done &done, const VrViewK &v, UnionSink &sink,
+                                                 uint32_t *length_out, uint32_t n_rounds)
+{
+    if (sink.pend) {
+        VR_WC(12);
+        UOPS::restart(U, stack, done, v, sink.pend_t, sink.pend_cell, sink.pend_runs);
+        sink.pend_shift();
+        return true;
+    }
+    if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], n_rounds);
+    return false;
+}
+
 template <class UOPS>
 __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top, uint32_t stack_rows, const float4 *__restrict__ ray_dt,
@@ -1583,50 +1430,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     /* lengths are kept only for lists the pre-pass would order (one atomic per item adds up on long lists) */
     uint32_t *const length_out = tile_cost && keep_lengths && ((n_active + 63u) >> 6) <= lpt_max_tiles(gridDim.x * kTraceThreads) ? tile_cost : nullptr;
     uint32_t n_rounds = 0; /* rounds this lane has spent on its item: the item's length, kept per tile for the next launch's order */
-#ifdef VR_MEASURE_ITEMS
-    uint32_t m_slot = 0, m_t0 = 0, m_rounds = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { g_item_dims[0] = n_active; g_item_dims[1] = n_blocks; g_item_dims[2] = block_isos; g_item_dims[3] = iso_begin; }
-#define VR_MEASURE_ITEM_END() do { if (m_slot < kMeasureItemsCap) { atomicMax(&g_item_rounds[m_slot], m_rounds); \
-        atomicMax(&g_item_ticks[m_slot], (uint32_t)__builtin_amdgcn_s_memrealtime() - m_t0); } } while (0)
-#else
-#define VR_MEASURE_ITEM_END() do { } while (0)
-#endif
-#ifdef VR_DIAG
-    uint32_t d_round = 0;
-    unsigned long long d_n = 0, d_c1 = 0, d_c2 = 0, d_c3 = 0, d_c4 = 0, d_l1 = 0, d_l2 = 0, d_l3 = 0, d_l4 = 0;
-    uint32_t d_res = 0, d_nres = 0;
-#endif
+    VR_MEASURE_LANE(measure);
+    VR_MEASURE_DIMS(n_active, n_blocks, block_isos, iso_begin);
     bool alive = false, exhausted = false, popping = false, suspect = false;
-    /* the front of a lane is finished: on with the iso values it has kept, if any, else the lane is idle (a macro, not
-     * a lambda taking the two flags by reference: that kept them in scratch memory) */
-#ifdef VR_LPT_TICKS /* measuring build: an item's length in ticks of the 100 MHz clock instead of rounds */
-#define VR_ITEM_BEGIN() ((uint32_t)__builtin_amdgcn_s_memrealtime())
-#define VR_ITEM_ROUND(rounds) (rounds)
-#define VR_ITEM_LENGTH(rounds) ((uint32_t)__builtin_amdgcn_s_memrealtime() - (rounds))
-#else
-#define VR_ITEM_BEGIN() 0u
-#define VR_ITEM_ROUND(rounds) ((rounds) + 1u)
-#define VR_ITEM_LENGTH(rounds) (rounds)
-#endif
-#ifdef VR_LPT_PARTS /* measuring build: every front on its own, not the lane's whole item */
-#define VR_ITEM_PART() do { if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], VR_ITEM_LENGTH(n_rounds)); n_rounds = VR_ITEM_BEGIN(); } while (0)
-#else
-#define VR_ITEM_PART() do { } while (0)
-#endif
-#define VR_FRONT_DONE()                                                                                     \
-    do {                                                                                                    \
-        if (sink.pend) {                                                                                    \
-            VR_WC(12);                                                                                      \
-            UOPS::restart(U, stack, done, v, sink.pend_t, sink.pend_cell, sink.pend_runs);                  \
-            sink.pend_shift();                                                                              \
-            popping = false;                                                                                \
-            VR_ITEM_PART();                                                                                 \
-        } else {                                                                                            \
-            alive = false;                                                                                  \
-            if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], VR_ITEM_LENGTH(n_rounds)); \
-            VR_MEASURE_ITEM_END();                                                                          \
-        }                                                                                                   \
-    } while (0)
 
     for (;;) {
         /* ---- refill idle lanes from the ray queue ---- */
@@ -1657,57 +1463,24 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             sink.pix = ray_pix[s_ray];
             sink.ray = s_ray;
             UOPS::begin(U, stack, done, v, ray_dt[s_ray], s_iso, s_n);
-            alive = true; popping = false; n_states = 0; n_rounds = VR_ITEM_BEGIN();
-#ifdef VR_MEASURE_ITEMS
-            m_slot = s_ray * n_blocks + (s_iso - iso_begin) / block_isos; m_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime(); m_rounds = 0;
-            if (m_slot < kMeasureItemsCap) g_item_begin[m_slot] = m_t0 - (uint32_t)tick_begin + 1u;
-#endif
+            alive = true; popping = false; n_states = 0; n_rounds = 0;
+            VR_MEASURE_DO(measure.begin(s_ray * n_blocks + (s_iso - iso_begin) / block_isos, tick_begin));
         }
         if (__ballot(alive) == 0ull) {
             if (exhausted) break;
             continue; /* fewer idle lanes than a refill takes cannot happen with nobody alive, but stay safe */
         }
-#ifdef VR_DIAG
-        {
-            const unsigned long long d_alive = __ballot(alive);
-            if (lane == 0 && (++d_round & 15u) == 0u) { /* every 16th round of a wave is sampled */
-                uint32_t b = (uint32_t)((__builtin_amdgcn_s_memrealtime() - tick_begin) / 2000ull);
-                b = b < 127u ? b : 127u;
-                atomicAdd(&g_union_hist[3u * b], (unsigned long long)__popcll(d_alive));
-                atomicAdd(&g_union_hist[3u * b + 1u], 1ull);
-            }
-        }
-#endif
-#ifdef VR_DIAG
-        const unsigned long long d_t0 = __builtin_amdgcn_s_memtime();
-        unsigned long long d_t1 = d_t0, d_t2 = d_t0;
-        const uint32_t d_desc = wave_sum(alive && !popping ? 1u : 0u), d_fronts = (uint32_t)__popcll(__ballot(alive));
-#endif
+        VR_MEASURE_DO(measure.round(alive, popping, tick_begin));
         if (alive) {
-            n_rounds = VR_ITEM_ROUND(n_rounds);
-#ifdef VR_MEASURE_ITEMS
-            m_rounds++;
-#endif
-        }
-#ifdef VR_MEASURE_ITEMS
-        {
-            const uint32_t t_alive = (uint32_t)__popcll(__ballot(alive)), t_desc = (uint32_t)__popcll(__ballot(alive && !popping));
-            if (alive && m_slot == g_trace_slot) {
-                const uint32_t at = atomicAdd(&g_trace_n, 1u);
-                if (at < 4096u) { g_trace[2u * at] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tick_begin); g_trace[2u * at + 1u] = t_alive | (t_desc << 8) | ((uint32_t)popping << 16) | (m_rounds << 20); }
-            }
-        }
-#endif
-        if (alive) {
+            n_rounds++;
             uint32_t go = VR_GO_MORE;
             if (!popping) go = UOPS::descend(U, fetch, stack, done, sink);
-#ifdef VR_DIAG
-            d_t1 = __builtin_amdgcn_s_memtime();
-#endif
             if (go == VR_GO_EXCLUDED) {
                 VR_WC(19);
-                if (U.alive_lo > U.alive_hi) {
-                    VR_FRONT_DONE(); /* every iso value of the front has hit */
+                if (U.alive_lo > U.alive_hi) { /* every iso value of the front has hit */
+                    alive = union_front_done<UOPS>(U, stack, done, v, sink, length_out, n_rounds);
+                    popping = false;
+                    if (!alive) VR_MEASURE_DO(measure.end());
                 } else {
                     depth_k = UOPS::depth(U, stack); cell_before = UOPS::cell(U);
                     x = UOPS::move(U, v);
@@ -1716,61 +1489,40 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                         sink.except_count[1] = 1u;
                         sink.pend = false; sink.pend2 = false; sink.pend3 = false;
                         alive = false;
-                        if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], VR_ITEM_LENGTH(n_rounds));
-                        VR_MEASURE_ITEM_END();
+                        if (length_out) atomicMax(&length_out[(size_t)(sink.ray >> 6) * kLptStride], n_rounds);
+                        VR_MEASURE_DO(measure.end());
                     } else if (!x.in_root) {
                         /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
                         const float t_new = U.L.t;
                         UOPS::leave(U, stack, x, suspect);
-#ifdef VR_DIAG
-                        const unsigned long long d_r0 = __builtin_amdgcn_s_memtime();
-#endif
                         if (suspect) UOPS::resolve(U, v, fetch, done, sink, depth_k, cell_before, -1, t_new, 0u, false, UOPS::root(v));
-#ifdef VR_DIAG
-                        if (suspect) { d_res += (uint32_t)(__builtin_amdgcn_s_memtime() - d_r0); d_nres++; }
-#endif
                         else vr_union_credit_esc(done, U, sink, 0u, 255u, x.esc);
                         if (U.alive_lo <= U.alive_hi)
                             vr_union_runs(done, U.alive_lo, U.alive_hi, [&](uint32_t r0, uint32_t r1) { sink.miss(r0, r1); }, U.holes);
-                        VR_FRONT_DONE();
+                        alive = union_front_done<UOPS>(U, stack, done, v, sink, length_out, n_rounds);
+                        popping = false;
+                        if (!alive) VR_MEASURE_DO(measure.end());
                     } else {
                         popping = true;
                     }
                 }
             }
-#ifdef VR_DIAG
-            d_t2 = __builtin_amdgcn_s_memtime();
-#endif
             if (popping && alive) {
                 VR_WC(18);
                 VrUnionFrom from = UOPS::root(v);
                 if (UOPS::pop(U, stack, x, suspect, from)) {
                     popping = false;
-#ifdef VR_DIAG
-                    const unsigned long long d_r0 = __builtin_amdgcn_s_memtime();
-#endif
                     if (suspect)
                         UOPS::resolve(U, v, fetch, done, sink, depth_k, cell_before, (int)UOPS::depth(U, stack) - 1, U.L.t, UOPS::cell(U), true, from);
-#ifdef VR_DIAG
-                    if (suspect) { d_res += (uint32_t)(__builtin_amdgcn_s_memtime() - d_r0); d_nres++; }
-#endif
                     UOPS::after_pop(U, fetch);
                     if (!suspect) vr_union_credit_esc(done, U, sink, U.prev_mn, U.prev_mx, x.esc);
-                    if (U.alive_lo > U.alive_hi) VR_FRONT_DONE();
+                    if (U.alive_lo > U.alive_hi) {
+                        alive = union_front_done<UOPS>(U, stack, done, v, sink, length_out, n_rounds);
+                        if (!alive) VR_MEASURE_DO(measure.end());
+                    }
                 }
             }
         }
-#ifdef VR_DIAG
-        {
-            /* the stamps are taken by the lanes that were alive; the wave's figure is the latest of them */
-            const unsigned long long d_t3 = __builtin_amdgcn_s_memtime();
-            const uint32_t a = wave_max((uint32_t)(d_t1 - d_t0)), b = wave_max((uint32_t)(d_t2 - d_t0)), c = (uint32_t)(d_t3 - d_t0);
-            d_n++; d_c1 += a; d_c2 += b - a; d_c3 += c - b; d_l1 += d_desc; d_l2 += d_fronts;
-            const uint32_t r = wave_max(d_res), nr = wave_sum(d_nres); /* the longest resolution of the round, and how many there were */
-            d_c4 += r; d_l3 += nr; d_l4 += nr ? 1u : 0u;
-            d_res = 0; d_nres = 0;
-        }
-#endif
         /* ---- a run that has left a lane's front goes to an idle lane of the wave, if there is one: a front of its own,
          * walked at the same time instead of after the ray's front (which is often the longest of the wave) ---- */
         for (;;) {
@@ -1786,28 +1538,16 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             g_runs.w23 = (uint32_t)__builtin_amdgcn_readlane((int)sink.pend_runs.w23, giver);
             const uint32_t g_pix = (uint32_t)__builtin_amdgcn_readlane((int)sink.pix, giver);
             const uint32_t g_ray = (uint32_t)__builtin_amdgcn_readlane((int)sink.ray, giver);
-#ifdef VR_MEASURE_ITEMS /* the run goes on as a part of the giver's item: its chain of rounds is the giver's so far plus the taker's */
-            const uint32_t g_slot = (uint32_t)__builtin_amdgcn_readlane((int)m_slot, giver), g_t0 = (uint32_t)__builtin_amdgcn_readlane((int)m_t0, giver);
-            const uint32_t g_rounds = (uint32_t)__builtin_amdgcn_readlane((int)m_rounds, giver);
-            if (lane == taker) { m_slot = g_slot; m_t0 = g_t0; m_rounds = g_rounds; }
-#endif
+            VR_MEASURE_DO(measure.hand_over(giver, lane == taker));
             UOPS::Ray::adopt(U.L, giver, lane == taker);
             if (lane == giver) sink.pend_shift();
             if (lane == taker) {
                 sink.pix = g_pix; sink.ray = g_ray;
                 UOPS::restart(U, stack, done, v, g_t, g_cell, g_runs);
-                alive = true; popping = false; n_states = 0; n_rounds = VR_ITEM_BEGIN();
+                alive = true; popping = false; n_states = 0; n_rounds = 0;
             }
         }
     }
-#ifdef VR_DIAG
-    if (lane == 0) {
-        const uint32_t b = (uint32_t)((__builtin_amdgcn_s_memrealtime() - tick_begin) / 2000ull);
-        atomicAdd(&g_union_hist[3u * (b < 127u ? b : 127u) + 2u], 1ull);
-        atomicAdd(&g_diag[0], d_n); atomicAdd(&g_diag[1], d_c1); atomicAdd(&g_diag[2], d_c2); atomicAdd(&g_diag[3], d_c3);
-        atomicAdd(&g_diag[4], d_l1); atomicAdd(&g_diag[5], d_l2); atomicAdd(&g_diag[6], d_c4); atomicAdd(&g_diag[7], d_l3); atomicAdd(&g_diag[8], d_l4);
-    }
-#endif
 
     {
         const uint32_t w_walks = wave_sum(n_walks);
@@ -1848,12 +1588,6 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     }
 }
 
-#undef VR_FRONT_DONE
-#undef VR_MEASURE_ITEM_END
-#undef VR_ITEM_LENGTH
-#undef VR_ITEM_BEGIN
-#undef VR_ITEM_ROUND
-#undef VR_ITEM_PART
 
 /* The union kernel asked for the call to be rendered again (kUnionRedoWord): every block of the fix kernel's grid clears its
  * share of the frames, and the first one puts the per-iso counters and the queue heads back to where the pre-pass left them. */
@@ -2092,10 +1826,6 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
     const uint32_t n_waves = gridDim.x * waves_per_block, gw = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const uint32_t k0 = (uint32_t)(((uint64_t)gw * iso_count) / n_waves);
     const uint32_t chunk_rays = trace_chunk(n_active, n_waves);
-#ifdef VR_DIAG
-    unsigned long long d_acc[20] = { 0 };
-    DIAG_T(d_begin);
-#endif
 
     for (uint32_t visit = 0; visit < iso_count; visit++) {
         uint32_t k = k0 + visit;
@@ -2112,7 +1842,6 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
         uint32_t a_hit = 0, a_miss = 0, a_moves = 0, a_esc = 0, a_err = 0;
 
         for (;;) {
-            DIAG_T(d_t0);
             const unsigned long long idle = __ballot(!alive);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (!exhausted && n_idle >= kRefillMin) {
@@ -2129,13 +1858,6 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
                 exhausted = chunk.exhausted();
             }
             if (__ballot(alive) == 0ull) break; /* only possible once the queue is exhausted */
-            DIAG_T(d_t1);
-            DIAG_ADD(0, d_t1 - d_t0);
-            DIAG_ADD(5, 1);
-            DIAG_ADD(10, __popcll(__ballot(alive)));
-#ifdef VR_DIAG
-            uint32_t d_go = VR_GO_MORE;
-#endif
 
             if (alive) {
                 uint32_t go = VR_GO_MORE;
@@ -2143,9 +1865,6 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
                 if (!popping) go = vr_wide_descend(L, v, iso, fetch, path, VR_WIDE_DESCEND_TRIPS);
 #else
                 if (!popping) { VrNoIsoTrack none; go = vr_wide_descend_ahead(L, v, iso, fetch, path, VR_WIDE_DESCEND_TRIPS, none); }
-#endif
-#ifdef VR_DIAG
-                d_go = go;
 #endif
                 if (go == VR_GO_HIT) { /* shade and store (src/raytrace.zig:56-61) */
                     const uint8_t g = vr_shade(L.t);
@@ -2186,28 +1905,10 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
                     }
                 }
             }
-#ifdef VR_DIAG
-            {
-                DIAG_T(d_t3);
-                DIAG_ADD(1, d_t3 - d_t1);
-                DIAG_ADD(3, wave_sum(d_go == VR_GO_EXCLUDED ? 1u : 0u));
-                DIAG_ADD(4, wave_sum(d_go == VR_GO_HIT ? 1u : 0u));
-                DIAG_ADD(2, wave_sum(d_go == VR_GO_MORE ? 1u : 0u));
-            }
-#endif
         }
 
         if (stats) wave_stats_out(stats, slots, k, gw, n_waves, lane, a_checked, a_hit, a_miss, a_esc, a_moves, a_err);
     }
-#ifdef VR_DIAG
-    {
-        DIAG_T(d_end);
-        d_acc[11] = d_end - d_begin;
-        d_acc[16] = 1;
-        if (lane == 0)
-            for (int i = 0; i < 20; i++) atomicAdd(&g_diag[i], d_acc[i]);
-    }
-#endif
 }
 
 /* workspace layout of the pipeline and its pre-pass (entry test once per call, dense ray list in tile order) */
@@ -2494,62 +2195,15 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                    : sweep ? (any_tap ? (const void *)vr_k_sweep<true, SweepNarrow> : (const void *)vr_k_sweep<false, SweepNarrow>)
                            : (any_tap ? (const void *)vr_k_trace<true> : (const void *)vr_k_trace<false>);
 
-#ifdef VR_MEASURE_ITEMS
-    if (use_union) {
-        void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
-        (void)hipGetSymbolAddress(&p0, HIP_SYMBOL(g_item_rounds)); (void)hipGetSymbolAddress(&p1, HIP_SYMBOL(g_item_ticks));
-        (void)hipGetSymbolAddress(&p2, HIP_SYMBOL(g_item_begin));
-        (void)hipMemsetAsync(p0, 0, sizeof(uint32_t) * kMeasureItemsCap, stream); (void)hipMemsetAsync(p1, 0, sizeof(uint32_t) * kMeasureItemsCap, stream);
-        (void)hipMemsetAsync(p2, 0, sizeof(uint32_t) * kMeasureItemsCap, stream);
-        if (getenv("VR_MEASURE_TRACE")) { /* VR_MEASURE_TRACE=ray,block,blocks per ray */
-            unsigned ray = 0, blk = 0, nb = 1;
-            if (sscanf(getenv("VR_MEASURE_TRACE"), "%u,%u,%u", &ray, &blk, &nb) == 3) {
-                const uint32_t slot = ray * nb + blk, zero = 0;
-                (void)hipStreamSynchronize(stream);
-                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_slot), &slot, 4); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, 4);
-            }
-        }
-    }
+#ifdef VR_MEASURE
+    if (use_union) vr_measure_before_launch(stream);
 #endif
     if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
     if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kTraceThreads), args, trace_lds, stream)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
-#ifdef VR_MEASURE_ITEMS
-    if (use_union && getenv("VR_MEASURE_DUMP")) { /* [dims: rays, blocks per ray, iso values per block, first iso][rounds][ticks][begin][pixel of every ray] as u32 */
-        (void)hipStreamSynchronize(stream);
-        uint32_t dims[4] = { 0, 0, 0, 0 };
-        (void)hipMemcpyFromSymbol(dims, HIP_SYMBOL(g_item_dims), sizeof dims);
-        const size_t n = (size_t)dims[0] * dims[1] < kMeasureItemsCap ? (size_t)dims[0] * dims[1] : kMeasureItemsCap;
-        std::vector<uint32_t> buf(n);
-        if (FILE *f = fopen(getenv("VR_MEASURE_DUMP"), "wb")) {
-            fwrite(dims, sizeof dims, 1, f);
-            (void)hipMemcpyFromSymbol(buf.data(), HIP_SYMBOL(g_item_rounds), n * sizeof(uint32_t)); fwrite(buf.data(), sizeof(uint32_t), n, f);
-            (void)hipMemcpyFromSymbol(buf.data(), HIP_SYMBOL(g_item_ticks), n * sizeof(uint32_t)); fwrite(buf.data(), sizeof(uint32_t), n, f);
-            (void)hipMemcpyFromSymbol(buf.data(), HIP_SYMBOL(g_item_begin), n * sizeof(uint32_t)); fwrite(buf.data(), sizeof(uint32_t), n, f);
-            buf.resize(dims[0]);
-            (void)hipMemcpy(buf.data(), ray_pix, (size_t)dims[0] * sizeof(uint32_t), hipMemcpyDeviceToHost); fwrite(buf.data(), sizeof(uint32_t), dims[0], f);
-            fclose(f);
-        }
-        {
-            unsigned long long c[24], z[24] = { 0 };
-            (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_wave_counts), sizeof c); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_counts), z, sizeof z);
-            static const char *what[24] = { "descend trips", "low-side parks", "high-side parks", "iterations of the run loop (done bits)", "done words read by the does-anybody-hold test",
-                "leaves", "iterations of the pixel-store loop", "MOVEs", "iterations of the escape loop", "levels left on the way out of the volume", "levels of exact resolutions",
-                "pop trips", "fronts restarted from kept runs", "refills", "hand-overs", "rounds", "hit runs", "items begun", "pop phases", "ends of a descent" };
-            fprintf(stderr, "[wave counts: how often a wave ran through a piece of the lane code, all launches since the last dump]\n");
-            for (int i = 0; i < 20; i++) fprintf(stderr, "  %-50s %12llu  (%.2f per round)\n", what[i], c[i], c[15] ? (double)c[i] / (double)c[15] : 0.0);
-        }
-        if (getenv("VR_MEASURE_TRACE") && getenv("VR_MEASURE_TRACE_OUT")) {
-            uint32_t n = 0; static uint32_t tr[2 * 4096];
-            (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), 4); (void)hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof tr);
-            if (FILE *f = fopen(getenv("VR_MEASURE_TRACE_OUT"), "w")) {
-                for (uint32_t i = 0; i < n && i < 4096u; i++)
-                    fprintf(f, "%u %.2f %u %u %u\n", tr[2 * i + 1] >> 20, tr[2 * i] / 100.0, tr[2 * i + 1] & 255u, (tr[2 * i + 1] >> 8) & 255u, (tr[2 * i + 1] >> 16) & 1u);
-                fclose(f);
-            }
-        }
-    }
+#ifdef VR_MEASURE
+    if (use_union) vr_measure_after_launch(stream, ray_pix);
 #endif
     if (use_union) { /* the few iso values whose own MOVE parted from the front's */
         if ((e = union_force_redo(stream, n_active)) != hipSuccess) return e;
@@ -2575,76 +2229,6 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
         hipLaunchKernelGGL(vr_k_sum_slots, dim3(iso_count), dim3(1024), 0, stream, slots, blocks * (kTraceThreads / 64u), d_stats);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-#ifdef VR_DIAG
-    {
-        unsigned long long h[20], z[20] = { 0 };
-        (void)hipStreamSynchronize(stream);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z);
-        if (use_union) {
-            fprintf(stderr, "[diag union] rounds %llu; cycles per round: descend %.0f, MOVE / leave / resolve %.0f, pop %.0f; lanes descending per round %.1f, fronts %.1f\n",
-                    h[0], (double)h[1] / (double)h[0], (double)h[2] / (double)h[0], (double)h[3] / (double)h[0], (double)h[4] / (double)h[0],
-                    (double)h[5] / (double)h[0]);
-            fprintf(stderr, "[diag union] exact resolutions: %.2f per round, rounds with one %.0f%%, cycles of the longest one per round %.0f\n",
-                    (double)h[7] / (double)h[0], 100.0 * (double)h[8] / (double)h[0], (double)h[6] / (double)h[0]);
-            static unsigned long long uh[3 * 128], uz[3 * 128];
-            (void)hipMemcpyFromSymbol(uh, HIP_SYMBOL(g_union_hist), sizeof uh);
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_union_hist), uz, sizeof uz);
-            unsigned long long ended = 0;
-            fprintf(stderr, "[diag union] per 20 us of the launch: sampled rounds (1 in 16), lanes with a front per round, waves ended so far\n");
-            for (int b = 0; b < 128; b++) {
-                ended += uh[3 * b + 2];
-                if (uh[3 * b + 1] || uh[3 * b + 2])
-                    fprintf(stderr, "[diag union] %4d us  rounds %6llu  fronts/round %5.1f  ended %llu\n", b * 20, uh[3 * b + 1],
-                            uh[3 * b + 1] ? (double)uh[3 * b] / (double)uh[3 * b + 1] : 0.0, ended);
-            }
-        } else if (sweep) {
-            static unsigned long long span[3 * 8192];
-            (void)hipMemcpyFromSymbol(span, HIP_SYMBOL(g_wave_span), sizeof span);
-            const uint32_t nw = (uint32_t)h[3] < 8192u ? (uint32_t)h[3] : 8192u;
-            unsigned long long t_min = ~0ull, t_max = 0;
-            for (uint32_t i = 0; i < nw; i++) { if (span[3 * i] < t_min) t_min = span[3 * i]; if (span[3 * i + 2] > t_max) t_max = span[3 * i + 2]; }
-            uint32_t hist_end[10] = { 0 }, hist_exh[10] = { 0 };
-            for (uint32_t i = 0; i < nw; i++) {
-                hist_end[(uint32_t)(9.999 * (double)(span[3 * i + 2] - t_min) / (double)(t_max - t_min))]++;
-                hist_exh[(uint32_t)(9.999 * (double)(span[3 * i + 1] - t_min) / (double)(t_max - t_min))]++;
-            }
-            fprintf(stderr, "[diag sweep] kernel span %llu x 10 ns; waves by end time (deciles of the span):", t_max - t_min);
-            for (int i = 0; i < 10; i++) fprintf(stderr, " %u", hist_end[i]);
-            fprintf(stderr, "\n[diag sweep] waves by the time they found the queue empty:");
-            for (int i = 0; i < 10; i++) fprintf(stderr, " %u", hist_exh[i]);
-            fprintf(stderr, "\n");
-            const double w = (double)h[3];
-            fprintf(stderr,
-                    "[diag sweep] waves %.0f  mean cycles/wave %.0f  slowest wave %.0f  mean cycles until the queue was empty %.0f (%.0f%%)\n"
-                    "[diag sweep] rounds/wave %.0f  alive lanes/round %.1f  traversals %.0f (%.1f per lane)  hit pixels written %.0f\n",
-                    w, h[1] / w, (double)h[19], h[0] / w, 100.0 * h[0] / (double)h[1], h[4] / w, h[5] / (double)h[4], (double)h[6],
-                    h[6] / (w * 64.0), (double)h[8]);
-            fprintf(stderr, "[diag sweep] after the queue was empty: rounds/wave %.0f, alive lanes/round %.1f, hand-overs/wave %.1f\n",
-                    h[10] / w, h[11] / (double)(h[10] ? h[10] : 1), h[9] / w);
-            {
-                const double it = (double)h[4];
-                fprintf(stderr,
-                        "[diag sweep] lanes per round: descending %.1f, moving %.1f, popping %.1f, ending a walk %.2f (rounds with one %.0f%%)\n"
-                        "[diag sweep] cycles per round: descend %.0f, move %.0f, pop %.0f, walk end %.0f, refill + hand-overs %.0f\n",
-                        h[2] / it, h[7] / it, h[12] / it, h[13] / it, 100.0 * h[18] / it, h[14] / it, h[15] / it, h[16] / it, h[17] / it,
-                        ((double)h[1] - (double)(h[14] + h[15] + h[16] + h[17])) / it);
-            }
-        } else {
-        const double w = (double)h[16], it = (double)h[5];
-        fprintf(stderr,
-                "[diag] waves %.0f  cycles/wave %.0f  rounds/wave %.0f  refill events/wave %.0f\n"
-                "[diag] per round: refill %.0f cyc, rest %.0f cyc; alive lanes %.1f\n"
-                "[diag] lanes per round: descending %.1f, moving %.1f (rounds with a move %.0f%%), popping %.1f\n"
-                "[diag] descend trips per round: wave max %.2f, mean over descending lanes %.2f\n"
-                "[diag] pop trips per round: wave max %.2f, mean over popping lanes %.2f\n"
-                "[diag] cycles per round: descend %.0f (%.0f per trip), move + store %.0f, pop %.0f (%.0f per trip)\n",
-                w, h[11] / w, it / w, h[17] / w, h[0] / it, h[1] / it, h[10] / it, h[2] / it, h[3] / it,
-                100.0 * h[14] / it, h[4] / it, h[6] / it, h[7] / (double)h[2], h[8] / it, h[9] / (double)h[4],
-                h[15] / it, h[15] / (double)h[6], h[13] / it, h[12] / it, h[12] / (double)h[8]);
-        }
-    }
-#endif
     return hipSuccess;
 }
 
@@ -2744,19 +2328,5 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         hipLaunchKernelGGL(vr_k_sum_slots, dim3(iso_count), dim3(1024), 0, stream, slots, blocks * (kWideThreads / 64u), d_stats);
         e = hipGetLastError();
     }
-#ifdef VR_DIAG
-    {
-        unsigned long long h[20], z[20] = { 0 };
-        (void)hipStreamSynchronize(stream);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z);
-        const double w = (double)h[16], it = (double)h[5];
-        fprintf(stderr,
-                "[diag wide] waves %.0f  cycles/wave %.0f  rounds/wave %.0f\n"
-                "[diag wide] per round: refill %.0f cyc, rest %.0f cyc; alive lanes %.1f; lanes ending the round in: "
-                "descend unfinished %.1f, excluded (MOVE) %.1f, hit %.2f\n",
-                w, h[11] / w, it / w, h[0] / it, h[1] / it, h[10] / it, h[2] / it, h[3] / it, h[4] / it);
-    }
-#endif
     return e;
 }

@@ -39,8 +39,8 @@
 /* The lane code of a front is large (runs of iso values, both sides of a range, exact resolution): the level loop is
  * not unrolled, so that the kernel's loop stays inside the instruction cache.  (Nothing is called out of line: a call
  * makes the kernel use scratch memory, and with scratch the whole grid is no longer resident at once.) */
-/* measuring builds count how often a wave runs through a piece of the lane code (VR_WC(i): one count per wave, whatever the
- * number of its lanes that are there); the product build compiles it to nothing */
+/* the measuring build counts how often a wave runs through a piece of the lane code (VR_WC(i), vr_measure.h); everywhere
+ * else -- the product library, the CPU emulation of the tests -- it is nothing */
 #ifndef VR_WC
 #define VR_WC(i) do { } while (0)
 #endif
