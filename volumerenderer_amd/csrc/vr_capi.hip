@@ -1051,4 +1051,26 @@ const char *vr_kernel_name(int variant)
     }
 }
 
+#ifdef VR_MEASURE
+/* measuring build only (not declared in vr.h): the step-by-step timeline of one ray; out = 25 u64, lat = 4096 u32 (host) */
+int vr_measure_ray_timeline(vr_ctx *c, const vr_view *view, uint8_t isoval, uint32_t xi, uint32_t yi, unsigned long long *out, uint32_t *lat)
+{
+    if (!c || !out || !lat || check_view(view) != VR_OK || !c->d_prepared || c->wide) return VR_EARG;
+    VR_HIP(hipSetDevice(c->device));
+    const VrViewK k = make_view(c, view);
+    unsigned long long *d_out = nullptr;
+    uint32_t *d_lat = nullptr;
+    hipError_t e = hipMalloc((void **)&d_out, 25 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_lat, 4096 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, 25 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = vr_launch_ray_timeline(c->stream, k, c->d_prepared, c->max_depth, xi, yi, isoval, d_out, d_lat);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, 25 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(lat, d_lat, 4096 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (d_out) (void)hipFree(d_out);
+    if (d_lat) (void)hipFree(d_lat);
+    return e == hipSuccess ? VR_OK : VR_EHIP_BASE - (int)e;
+}
+#endif
+
 } // extern "C"

@@ -131,4 +131,10 @@ hipError_t vr_launch_refine(hipStream_t stream, const VrViewK &view, bool wide, 
                             uint32_t row_begin, uint32_t n_rows, uint32_t n_frames, const uint32_t *d_cell_flag, const float *d_t,
                             float *d_density);
 
+#ifdef VR_MEASURE
+/* measuring build: one ray walked by one lane with every step stamped (vr_k_ray_timeline) */
+hipError_t vr_launch_ray_timeline(hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t xi,
+                                  uint32_t yi, uint32_t iso, unsigned long long *d_out, uint32_t *d_lat);
+#endif
+
 #endif

@@ -1911,6 +1911,124 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
     }
 }
 
+#ifdef VR_MEASURE
+/* Measuring build: ONE ray of one iso value walked by ONE lane of one wave with the lane code of the pipeline kernel (resume
+ * traversal, top tree levels in LDS, the same flat node fetch), every step bracketed by cycle stamps with all memory operations
+ * waited for at each stamp -- the latency chain of a walk with nothing else on the chip.  out[]: per kind of step (0 node fetch
+ * from the LDS copy, 1 node fetch from global memory, 2 rest of a descend level: range test, child choice, box update, push,
+ * 3 MOVE with its escape loop, 4 one popped level, 5 entering the sibling at the end of a pop, 6 loop bookkeeping between the
+ * steps) the number of steps and the sum of their cycles; out[20] the whole walk, out[21] checks, out[22] MOVEs, out[23] flag;
+ * lat[]: the first 4096 node fetches as cycles | from_global << 20 | level << 24. */
+__global__ __launch_bounds__(64) void vr_k_ray_timeline(VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top, uint32_t stack_rows,
+                                                        uint32_t xi, uint32_t yi, uint32_t iso, unsigned long long *__restrict__ out,
+                                                        uint32_t *__restrict__ lat)
+{
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t *s_top = s_dyn + stack_rows * 64u;
+    uint32_t *s_lat = s_top + n_top; /* 4096 words: the table is kept in LDS during the walk and copied out behind it */
+    for (uint32_t i = threadIdx.x; i < n_top; i += 64u) s_top[i] = nodes[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    LdsStack<64u> st;
+    const TopFetch fetch(nodes, s_top, n_top, v.n_slots);
+    const VrRay ray = vr_make_ray(v, xi, yi);
+    /* scalars, not an array: an array indexed at run time would live in scratch memory and its traffic in the stamps */
+    unsigned long long c_lds = 0, c_glb = 0, c_rest = 0, c_move = 0, c_pop = 0, c_sib = 0, c_book = 0;
+    uint32_t n_lds = 0, n_glb = 0, n_rest = 0, n_move = 0, n_pop = 0, n_sib = 0;
+    uint32_t n_lat = 0, moves = 0, esc = 0, flag = ray.oob ? 2u : 0u;
+#define VR_STAMP(var) __builtin_amdgcn_s_waitcnt(0); const unsigned long long var = __builtin_amdgcn_s_memtime()
+    VrLane L;
+    VR_STAMP(t_begin);
+    if (!ray.oob) {
+        vr_lane_begin(L, st, v, ray.dx, ray.dy, ray.dz, ray.t);
+        unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+        for (;;) {
+            /* ---- descend, level by level (vr_lane_descend, one trip at a time) ---- */
+            uint32_t go = VR_GO_MORE;
+            while (go == VR_GO_MORE) {
+                VR_STAMP(t0);
+                c_book += t0 - t_prev;
+                const uint32_t n = fetch(L.g);
+                asm volatile("" :: "v"(n));
+                VR_STAMP(t1);
+                L.checked++;
+                if (!vr_node_holds(n, iso)) go = VR_GO_EXCLUDED;
+                else if (n & VR_N_LEAF) go = VR_GO_HIT;
+                else {
+                    const uint32_t sh = (n >> 24) & 31u, part = (n >> 16) & 0xffu;
+                    const bool right = ((L.cell >> sh) & 0xffu) >= part;
+                    uint32_t side = right ? L.lo : L.hi;
+                    st.push(side);
+                    side = (side & ~(0xffu << sh)) | (part << sh);
+                    L.lo = right ? side : L.lo;
+                    L.hi = right ? L.hi : side;
+                    L.g = vr_twice_plus(L.g, right);
+                }
+                VR_STAMP(t2);
+                c_rest += t2 - t1; n_rest++;
+                /* bookkeeping of the measurement itself (counted as such): the fetch goes to the table */
+                const bool from_global = (go == VR_GO_MORE ? (L.g >> 1) : L.g) >= n_top;
+                if (from_global) { c_glb += t1 - t0; n_glb++; } else { c_lds += t1 - t0; n_lds++; }
+                if (n_lat < 4096u) s_lat[n_lat++] = (uint32_t)(t1 - t0 < 0xfffffu ? t1 - t0 : 0xfffffu) | ((from_global ? 1u : 0u) << 20) | ((st.depth() - (go == VR_GO_MORE ? 1u : 0u)) << 24);
+                t_prev = t2;
+            }
+            if (go == VR_GO_HIT) { flag = 1u; break; }
+            moves++;
+            VR_STAMP(t3);
+            c_book += t3 - t_prev;
+            const bool in_root = vr_lane_move(L, v, esc);
+            VR_STAMP(t4);
+            c_move += t4 - t3; n_move++;
+            t_prev = t4;
+            if (!in_root || moves > (1u << 20)) break;
+            bool entered = false;
+            while (!entered) {
+                VR_STAMP(t5);
+                c_book += t5 - t_prev;
+                const uint32_t d0 = st.depth();
+                entered = vr_lane_pop(L, st, 1u);
+                VR_STAMP(t6);
+                if (entered && st.depth() == d0) { c_sib += t6 - t5; n_sib++; } /* found at once: only the step into the sibling */
+                else { c_pop += t6 - t5; n_pop++; }
+                t_prev = t6;
+            }
+        }
+    }
+    VR_STAMP(t_end);
+    const uint32_t stamped_checked = ray.oob ? 0u : L.checked;
+    /* the same walk once more with nothing in between: the lane code as the kernels call it (bounded descend / pop phases) */
+    unsigned long long bare = 0;
+    uint32_t bare_checked = 0;
+    if (!ray.oob) {
+        uint32_t esc2 = 0, mv2 = 0;
+        VR_STAMP(b0);
+        vr_lane_begin(L, st, v, ray.dx, ray.dy, ray.dz, ray.t);
+        for (;;) {
+            const uint32_t go = vr_lane_descend(L, iso, fetch, st, kDescendTrips);
+            if (go == VR_GO_MORE) continue;
+            if (go == VR_GO_HIT) break;
+            if (++mv2 > (1u << 20) || !vr_lane_move(L, v, esc2)) break;
+            while (!vr_lane_pop(L, st, kPopTrips)) {}
+        }
+        VR_STAMP(b1);
+        bare = b1 - b0; bare_checked = L.checked;
+    }
+    /* what a stamp itself costs: the distance of two with nothing in between */
+    unsigned long long stamp_cost = 0;
+    for (int i = 0; i < 16; i++) {
+        VR_STAMP(s0);
+        VR_STAMP(s1);
+        stamp_cost += s1 - s0;
+    }
+#undef VR_STAMP
+    out[14] = bare; out[15] = bare_checked; out[16] = stamp_cost;
+    out[0] = c_lds; out[1] = n_lds; out[2] = c_glb; out[3] = n_glb; out[4] = c_rest; out[5] = n_rest; out[6] = c_move; out[7] = n_move;
+    out[8] = c_pop; out[9] = n_pop; out[10] = c_sib; out[11] = n_sib; out[12] = c_book; out[13] = n_rest;
+    out[20] = t_end - t_begin; out[21] = stamped_checked; out[22] = moves; out[23] = flag; out[24] = n_lat;
+    for (uint32_t i = 0; i < n_lat; i++) lat[i] = s_lat[i];
+}
+#endif
+
 /* workspace layout of the pipeline and its pre-pass (entry test once per call, dense ray list in tile order) */
 struct Prepass {
     float4 *ray_dt;
@@ -2330,3 +2448,17 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
     }
     return e;
 }
+
+#ifdef VR_MEASURE
+hipError_t vr_launch_ray_timeline(hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t xi,
+                                  uint32_t yi, uint32_t iso, unsigned long long *d_out, uint32_t *d_lat)
+{
+    const uint32_t stack_rows = (max_depth > 0 ? max_depth : 1u) + 1u;
+    uint32_t top_levels = 13; /* 32 KiB of top levels beside the one wave's stack, as vr_k_union_fix has them */
+    while (top_levels > 0 && ((uint64_t)1 << top_levels) > view.n_slots + 1u) top_levels--;
+    const uint32_t n_top = 1u << top_levels;
+    const size_t lds = ((size_t)stack_rows * 64u + n_top + 4096u) * sizeof(uint32_t);
+    hipLaunchKernelGGL(vr_k_ray_timeline, dim3(1), dim3(64), lds, stream, view, d_nodes_prepared, n_top, stack_rows, xi, yi, iso, d_out, d_lat);
+    return hipGetLastError();
+}
+#endif
