@@ -61,7 +61,7 @@ struct vr_ctx {
      * shortest of a few launches (three; two for the kernel with one traversal per ray, whose cut matters less).  For a new
      * workload the base cut runs first (8 items per lane for long sweeps, 3 for the union kernel, fewer for short sweeps:
      * sweep_cut_base; the very first launch, on cold caches, does not count), then the next smaller cut (3/4 of the base)
-     * and the next larger one (3/2), and on from the better of the two (1/2, 1/4 or 2x, 4x) while it pays.  A candidate gets
+     * and the next larger one (2x), and on from the better of the two (1/2, 1/4 or 4x, 8x) while it pays.  A candidate gets
      * exactly its launches, all other launches use the best cut known; it stays when it was at least 1.5 % shorter.  Results
      * never depend on the cut.
      * A workload is what decides the cut: tree, image size, number of rows and of iso values, kernel -- not the camera, the
@@ -466,10 +466,12 @@ static uint32_t sweep_cut_base(uint32_t iso_count, bool union_kernel = false)
     const uint32_t b = iso_count / 8u;
     return b < 2u ? 2u : (b > VR_SWEEP_ITEMS_DEFAULT ? VR_SWEEP_ITEMS_DEFAULT : b);
 }
-/* the step-th candidate below (dir < 0: 3/4, 1/2, 1/4 of the base) or above it (3/2, 2x, 4x); 0 = none left */
+/* the step-th candidate below (dir < 0: 3/4, 1/2, 1/4 of the base) or above it (2x, 4x, 8x: the time is flat between
+ * neighbouring cuts -- the 256^3 stand-in: 3.8 ms at 3 items per lane, 3.5 at 5, 3.4 at 6, 2.9 at 12 -- and a search in
+ * small steps stops on the plateau); 0 = none left */
 static uint32_t sweep_cut_candidate(uint32_t base, int dir, int step)
 {
-    static const uint32_t num[2][3] = { { 6u, 4u, 2u }, { 12u, 16u, 32u } };
+    static const uint32_t num[2][3] = { { 6u, 4u, 2u }, { 16u, 32u, 64u } };
     if (step > 2 || num[dir < 0 ? 0 : 1][step] == 0u) return 0u;
     const uint32_t c = (base * num[dir < 0 ? 0 : 1][step] + 4u) / 8u;
     const uint32_t prev = step == 0 ? base : (base * num[dir < 0 ? 0 : 1][step - 1] + 4u) / 8u;
