@@ -259,3 +259,45 @@ def test_union_kernel_context_remembers_several_calls(oracle, skull_vox):
             run(views[0], 0, 256, 8 * j, H)
         got = run(views[1], 0, 256)
         assert got[2].tiles_longest_first == 0 and bool(torch.equal(got[0], refs[1][0])) and (got[1] == refs[1][1]).all()
+
+
+def test_union_kernel_counters_on_a_move_heavy_volume_at_2048(oracle):
+    """Low noise with a few isolated dense voxels: large nodes hold the iso values, small ones exclude them, so every ray
+    MOVEs through dozens of small boxes before it meets a dense voxel; at 2048^2 the blocks of the grid then count hundreds of
+    thousands of MOVEs per iso value, which ride in the upper bits of their 64-bit check sums (kParkMoveShift).  Frames and
+    all 7 counters of the union kernel equal the kernel with one traversal per iso value; the same camera on a small image
+    equals the oracle."""
+    import torch
+    rng = np.random.default_rng(77)
+    vox = rng.integers(0, 100, size=(160, 160, 160), dtype=np.uint8)
+    vox[rng.random(vox.shape) < 0.002] = 255
+    pos, forw, up = oracle.main_camera(vox.shape)
+    L = capi.lib()
+    W = H = 2048
+    b, n = 92, 16  # iso values below 100 hold in the noise itself, the others only next to a dense voxel
+    with vr.Renderer(0) as r:
+        r.upload_volume(vr.Data(vox))
+        r.build_kdt("AlwaysCenter")
+        v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+        res = []
+        for variant in (capi.KERNEL_PIPELINE, capi.KERNEL_UNION):
+            r.set_kernel(variant)
+            d_rgb = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+            d_stats = torch.zeros((n, 7), dtype=torch.int64, device="cuda")
+            capi.check(L.vr_render_device(r.handle, C.byref(v), b, n, 0, H, d_rgb.data_ptr(), d_stats.data_ptr(), None, None), "vr_render_device")
+            capi.check(L.vr_sync(r.handle), "vr_sync")
+            res.append((d_rgb, d_stats.cpu().numpy()))
+        assert (res[0][1] == res[1][1]).all(), np.argwhere(res[0][1] != res[1][1])[:8]
+        assert bool(torch.equal(res[0][0], res[1][0]))
+        st = res[1][1]
+        assert int(st[:, 6].sum()) == 0
+        assert int(st[:, 5].max()) > 10 * (W * H - int(st[0, 3])), "the volume was meant to be MOVE-heavy: %d MOVEs for %d rays" % (
+            int(st[:, 5].max()), W * H - int(st[0, 3]))
+        # the same camera at 96 x 64 against the oracle, every iso value of the block
+        nodes, rd, _ = oracle.build_kdt(vox, "AlwaysCenter")
+        r.set_kernel(capi.KERNEL_UNION)
+        out = r.renderSweep(pos, forw, up, 96, 64, 2.0, b, n)
+        for j in range(n):
+            ref = oracle.render(nodes, rd, pos, forw, up, 96, 64, 2.0, b + j)
+            assert (out["rgb"][j] == ref["rgb"]).all()
+            _check_stats({"stats": out["stats"][j]}, ref)
