@@ -661,10 +661,16 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         }
         const size_t need = vr_pipeline_lpt_bytes(view->width, row_end - row_begin);
         if (need > lpt->cap) {
-            VR_HIP(hipStreamSynchronize(s)); /* an earlier launch may still use the buffer */
-            rc = ensure(&lpt->mem, &lpt->cap, need);
-            if (rc != VR_OK) { lpt->have = false; return rc; }
-            lpt->have = false; lpt->lengths_ipl = 0; lpt->order_ipl = 0;
+            /* Every entry of the table gets a buffer of this size now (at most 8 x 8.1 MiB): a caller whose every call is a new one
+             * -- a moving camera -- allocates on its first call and never again, like the rest of the context's scratch. */
+            VR_HIP(hipStreamSynchronize(s)); /* an earlier launch may still use a buffer */
+            for (int i = 0; i < vr_ctx::kRemember; i++) {
+                vr_ctx::LptEntry &u = c->lpts[i];
+                if (u.cap >= need) continue;
+                rc = ensure(&u.mem, &u.cap, need);
+                u.have = false; u.lengths_ipl = 0; u.order_ipl = 0;
+                if (rc != VR_OK) return rc;
+            }
         }
         vr_ctx::LptEntry &u = *lpt;
         if (u.have && u.order_ipl == ipl) {

@@ -247,6 +247,16 @@ __host__ __device__ __forceinline__ uint32_t padded_tiles(uint32_t width, uint32
     return super_tiles_x(width) * super_tiles_y(n_rows) * kSuper * kSuper;
 }
 
+/* column and row (inside the call's rows) of lane `lane` of tile `tile`; they may lie outside the image */
+__device__ __forceinline__ void tile_xy(const VrViewK &v, uint32_t tile, uint32_t lane, uint32_t n_rows, bool center_out, uint32_t &xi, uint32_t &yr)
+{
+    const uint32_t st = tile / (kSuper * kSuper), in = tile % (kSuper * kSuper), sx = super_tiles_x(v.width);
+    const uint32_t row_i = st / sx, mid = super_tiles_y(n_rows) / 2u;
+    const uint32_t row = !center_out ? row_i : ((row_i & 1u) ? mid - (row_i + 1u) / 2u : mid + row_i / 2u);
+    xi = ((st % sx) * kSuper + in % kSuper) * kTileW + (lane & 7u);
+    yr = (row * kSuper + in / kSuper) * kTileH + (lane >> 3);
+}
+
 __device__ __forceinline__ bool tile_ray(const VrViewK &v, uint32_t tile, uint32_t lane, uint32_t row_begin, uint32_t n_rows, bool center_out,
                                          VrRay &ray, uint32_t &pix)
 {
@@ -292,15 +302,31 @@ __device__ __forceinline__ bool pre_block(const VrViewK &v, uint32_t row_begin, 
     return active;
 }
 
-/* 1a: number of rays per super-tile that enter the root box */
+/* frames are cleared by a memset from this many iso values per call on, or when they hold more than this many pixels together
+ * (byte stores of a thread per pixel: 4096^2 takes 0.02 ms longer that way than the memset it saves) */
+constexpr uint32_t kCountClearsBelow = 8;
+constexpr size_t kCountClearsPixels = (size_t)4 << 20;
+
+/* 1a: number of rays per super-tile that enter the root box.  A call of a few iso values has its frames cleared here as well
+ * (clear_isos of them, a thread its own pixel: OOB and miss pixels are black, src/raytrace.zig:54,67) instead of by a memset of
+ * its own: one stream operation less in front of a kernel that takes a fraction of a millisecond. */
 __global__ __launch_bounds__(kPreThreads) void vr_k_count(VrViewK v, uint32_t row_begin, uint32_t n_rows, uint32_t center_out,
-                                                          uint32_t *__restrict__ block_count)
+                                                          uint32_t *__restrict__ block_count, uint8_t *__restrict__ rgb, uint32_t clear_isos)
 {
     VrRay ray;
     uint32_t pix, before, total;
     unsigned long long mask;
     (void)pre_block(v, row_begin, n_rows, center_out != 0u, ray, pix, mask, before, total);
     if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+    if (clear_isos) {
+        uint32_t xi, yr;
+        tile_xy(v, blockIdx.x * (kSuper * kSuper) + (threadIdx.x >> 6), threadIdx.x & 63u, n_rows, center_out != 0u, xi, yr);
+        if (xi < v.width && yr < n_rows) {
+            const uint64_t frame_bytes = (uint64_t)v.width * n_rows * 3u;
+            uint8_t *p = rgb + ((uint64_t)yr * v.width + xi) * 3u;
+            for (uint32_t k = 0; k < clear_isos; k++, p += frame_bytes) { p[0] = 0u; p[1] = 0u; p[2] = 0u; }
+        }
+    }
 }
 
 /* Order of the tiles (groups of 64 consecutive rays of the list) for a union launch that repeats the previous call:
@@ -546,23 +572,24 @@ constexpr uint32_t kTraceWavesPerSimd = kTraceThreads / 64u * kTraceBlocksPerCu 
 
 /* Per-iso counters of the kernels with one traversal per iso value.  With a handful of iso values every wave of
  * the grid would add to the same few words, and device-wide atomics on one address are served in series (about
- * 10 ns each: the backlog of 4096 waves x 6 counters outlasts a short kernel).  There each wave stores its sums
- * in a slot of its own (`slots`: [iso][wave] records) and vr_k_sum_slots adds them up afterwards; sweeps of many
- * iso values spread over as many records and use atomics. */
-constexpr uint32_t kSlotIsoMax = 8, kSlotWaveMax = 8192;
-struct WaveStats { unsigned long long checked; uint32_t hit, miss, esc, moves, err, pad; };
+ * 10 ns each: the backlog of 4096 waves x 6 counters outlasts a short kernel).  There the waves of a block add their
+ * sums up in LDS (`s_acc`: [iso value][counter]) and the block adds them to the counters once, at its end: 16 times
+ * fewer device-wide atomics, spread over the time in which the blocks end; sweeps of many iso values spread over as
+ * many records and use device-wide atomics straight away. */
+constexpr uint32_t kSlotIsoMax = 8;
 
-__device__ __forceinline__ void wave_stats_out(vr_render_stats *__restrict__ stats, WaveStats *__restrict__ slots, uint32_t k,
-                                               uint32_t gw, uint32_t n_waves, uint32_t lane, unsigned long long a_checked,
-                                               uint32_t a_hit, uint32_t a_miss, uint32_t a_esc, uint32_t a_moves, uint32_t a_err)
+__device__ __forceinline__ void wave_stats_out(vr_render_stats *__restrict__ stats, unsigned long long *s_acc, uint32_t k, uint32_t lane,
+                                               unsigned long long a_checked, uint32_t a_hit, uint32_t a_miss, uint32_t a_esc, uint32_t a_moves,
+                                               uint32_t a_err)
 {
     const unsigned long long c_checked = wave_sum64(a_checked);
     const uint32_t c_hit = wave_sum(a_hit), c_miss = wave_sum(a_miss), c_moves = wave_sum(a_moves);
     const uint32_t c_esc = wave_sum(a_esc), c_err = wave_sum(a_err);
     if (lane != 0) return;
-    if (slots) {
-        WaveStats w = { c_checked, c_hit, c_miss, c_esc, c_moves, c_err, 0u };
-        slots[(size_t)k * n_waves + gw] = w;
+    if (s_acc) {
+        unsigned long long *a = s_acc + k * 6u;
+        atomicAdd(&a[0], c_checked); atomicAdd(&a[1], (unsigned long long)c_hit); atomicAdd(&a[2], (unsigned long long)c_miss);
+        atomicAdd(&a[3], (unsigned long long)c_esc); atomicAdd(&a[4], (unsigned long long)c_moves); atomicAdd(&a[5], (unsigned long long)c_err);
         return;
     }
     vr_render_stats *s = stats + k;
@@ -574,30 +601,16 @@ __device__ __forceinline__ void wave_stats_out(vr_render_stats *__restrict__ sta
     add_stat(&s->errors, c_err);
 }
 
-/* one block per iso value: the sums of the waves' slots become the counters (oob_count was set by the scan kernel) */
-__global__ __launch_bounds__(1024) void vr_k_sum_slots(const WaveStats *__restrict__ slots, uint32_t n_waves,
-                                                       vr_render_stats *__restrict__ stats)
+/* the block's sums of a short iso range go to the counters (oob_count was set by the scan kernel); every thread of the block calls it */
+__device__ __forceinline__ void block_stats_out(vr_render_stats *__restrict__ stats, const unsigned long long *s_acc, uint32_t iso_count)
 {
-    __shared__ unsigned long long s_part[16][6];
-    const uint32_t k = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    unsigned long long a[6] = { 0, 0, 0, 0, 0, 0 };
-    for (uint32_t w = threadIdx.x; w < n_waves; w += 1024u) {
-        const WaveStats x = slots[(size_t)k * n_waves + w];
-        a[0] += x.checked; a[1] += x.hit; a[2] += x.miss; a[3] += x.esc; a[4] += x.moves; a[5] += x.err;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        a[i] = wave_sum64(a[i]);
-        if (lane == 0) s_part[wave][i] = a[i];
-    }
     __syncthreads();
-    if (threadIdx.x < 6) {
-        unsigned long long t = 0;
-        for (uint32_t w = 0; w < 16u; w++) t += s_part[w][threadIdx.x];
+    if (threadIdx.x < iso_count * 6u) {
+        const uint32_t k = threadIdx.x / 6u, i = threadIdx.x - k * 6u;
         vr_render_stats *s = stats + k;
-        uint64_t *dst = threadIdx.x == 0 ? &s->nodes_checked : threadIdx.x == 1 ? &s->hit_count : threadIdx.x == 2 ? &s->miss_count
-                      : threadIdx.x == 3 ? &s->escape_help_events : threadIdx.x == 4 ? &s->moves : &s->errors;
-        *dst = t;
+        uint64_t *dst = i == 0 ? &s->nodes_checked : i == 1 ? &s->hit_count : i == 2 ? &s->miss_count
+                      : i == 3 ? &s->escape_help_events : i == 4 ? &s->moves : &s->errors;
+        if (s_acc[threadIdx.x]) add_stat(dst, s_acc[threadIdx.x]);
     }
 }
 
@@ -668,10 +681,13 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
                                                             uint32_t *__restrict__ heads, uint32_t iso_begin,
                                                             uint32_t iso_count, uint64_t frame_pixels,
                                                             uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
-                                                            WaveStats *__restrict__ slots, VrTapsK taps)
+                                                            uint32_t block_counters, VrTapsK taps)
 {
     /* dynamic LDS: [path stacks: stack_rows x kTraceThreads words][n_top node words: heap positions 0 .. n_top-1] */
     extern __shared__ uint32_t s_dyn[];
+    __shared__ unsigned long long s_acc_mem[kSlotIsoMax * 6u]; /* the block's counter sums of a short iso range (block_counters) */
+    unsigned long long *const s_acc = block_counters ? s_acc_mem : nullptr;
+    if (threadIdx.x < kSlotIsoMax * 6u) s_acc_mem[threadIdx.x] = 0ull;
     uint32_t *s_top = s_dyn + stack_rows * kTraceThreads;
     for (uint32_t i = threadIdx.x; i < n_top; i += kTraceThreads) s_top[i] = nodes[i];
     __syncthreads();
@@ -771,8 +787,9 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_trace(
         }
 
         /* ---- per-iso counters ---- */
-        if (stats) wave_stats_out(stats, slots, k, gw, n_waves, lane, a_checked, a_hit, a_miss, a_esc, a_moves, a_err);
+        if (stats) wave_stats_out(stats, s_acc, k, lane, a_checked, a_hit, a_miss, a_esc, a_moves, a_err);
     }
+    if (stats && s_acc) block_stats_out(stats, s_acc, iso_count);
 }
 
 /* --------------------------------------------------------- pipeline: iso sweep kernel ---- */
@@ -1813,10 +1830,14 @@ template <bool TAPS>
 __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
     VrViewK v, const uint32_t *__restrict__ nodes, const float4 *__restrict__ ray_dt, const uint32_t *__restrict__ ray_pix,
     const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ heads, uint32_t iso_begin, uint32_t iso_count,
-    uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats, WaveStats *__restrict__ slots,
+    uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats, uint32_t block_counters,
     VrTapsK taps)
 {
     extern __shared__ uint32_t s_dyn[];
+    __shared__ unsigned long long s_acc_mem[kSlotIsoMax * 6u]; /* the block's counter sums of a short iso range (block_counters) */
+    unsigned long long *const s_acc = block_counters ? s_acc_mem : nullptr;
+    if (threadIdx.x < kSlotIsoMax * 6u) s_acc_mem[threadIdx.x] = 0ull;
+    __syncthreads();
     LdsPath<kWideThreads> path{ s_dyn + threadIdx.x };
     const WideFetch fetch{ nodes, (uint32_t)(v.n_slots - 2u) }; /* a wide tree has far more than two nodes */
 
@@ -1907,8 +1928,9 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
             }
         }
 
-        if (stats) wave_stats_out(stats, slots, k, gw, n_waves, lane, a_checked, a_hit, a_miss, a_esc, a_moves, a_err);
+        if (stats) wave_stats_out(stats, s_acc, k, lane, a_checked, a_hit, a_miss, a_esc, a_moves, a_err);
     }
+    if (stats && s_acc) block_stats_out(stats, s_acc, iso_count);
 }
 
 #ifdef VR_MEASURE
@@ -2033,7 +2055,6 @@ __global__ __launch_bounds__(64) void vr_k_ray_timeline(VrViewK v, const uint32_
 struct Prepass {
     float4 *ray_dt;
     uint32_t *ray_pix, *n_active, *heads;
-    WaveStats *slots; /* kSlotIsoMax x kSlotWaveMax records */
 };
 
 hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_count, uint32_t row_begin, uint32_t n_rows,
@@ -2052,14 +2073,14 @@ hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_
     w += ((size_t)n_blocks * sizeof(uint32_t) + 255) & ~(size_t)255;
     pp.n_active = (uint32_t *)w;
     w += 256;
-    pp.slots = (WaveStats *)w;
-    w += sizeof(WaveStats) * kSlotIsoMax * kSlotWaveMax;
     pp.heads = (uint32_t *)w;
 
     hipError_t e;
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
-    if ((e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(vr_k_count, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt);
+    /* the frames start black: a memset for sweeps, the count kernel's own threads for the few frames of a short call */
+    const uint32_t clear_isos = iso_count < kCountClearsBelow && n_pix * iso_count <= kCountClearsPixels ? iso_count : 0u;
+    if (!clear_isos && (e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(vr_k_count, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt, d_rgb, clear_isos);
     hipLaunchKernelGGL(vr_k_scan, dim3(tile_order ? 2 : 1), dim3(1024), 0, stream, block_cnt, n_blocks, pp.n_active, pp.heads, iso_count, d_stats,
                        (uint64_t)n_pix, (uint32_t)((n_pix + 63u) / 64u), tile_cost, tile_order, lpt_max_tiles(grid_lanes),
                        chord_order ? tile_cost - kLptHeaderWords : (uint32_t *)nullptr);
@@ -2102,8 +2123,11 @@ hipError_t vr_device_setup(int device)
                           (const void *)vr_k_sweep<false, SweepWide>,   (const void *)vr_k_sweep<true, SweepWide>,
                           (const void *)vr_k_trace_wide<false>, (const void *)vr_k_trace_wide<true>,
                           (const void *)vr_k_union<UnionNarrow>, (const void *)vr_k_union<UnionWide> };
-    for (const void *fn : fns)
-        if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u))) != hipSuccess) return e;
+    for (const void *fn : fns) { /* what is left of the CU's 160 KiB beside the kernel's static LDS (the trace kernels' counter sums) */
+        hipFuncAttributes attr;
+        if ((e = hipFuncGetAttributes(&attr, fn)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u - attr.sharedSizeBytes))) != hipSuccess) return e;
+    }
     void *p = nullptr;
     if ((e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch))) != hipSuccess) return e;
     if (!p) return hipErrorInvalidSymbol;
@@ -2136,7 +2160,6 @@ size_t vr_pipeline_workspace_bytes(uint32_t width, uint32_t n_rows, uint32_t iso
     bytes += (n_pix * sizeof(uint32_t) + 255) & ~(size_t)255; /* ray_pix    */
     bytes += (n_blocks * sizeof(uint32_t) + 255) & ~(size_t)255; /* super-tile count / offset */
     bytes += 256;                                               /* n_active   */
-    bytes += sizeof(WaveStats) * kSlotIsoMax * kSlotWaveMax;    /* per-wave counters of short iso ranges */
     bytes += ((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255; /* queue heads */
     bytes += (size_t)VR_UNION_EXCEPT_CAP * sizeof(VrUnionRecord);          /* iso runs that left a union walk */
     return bytes;
@@ -2283,7 +2306,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
      * left of its share of the CU's 160 KiB, the top K levels of the tree (two thirds of all node reads).
      * More than one iso value: the sweep kernel, which shares traversals between iso values. */
     const size_t trace_stack_bytes = ((size_t)stack_levels + 1u) * kTraceThreads * sizeof(uint32_t);
-    const size_t stat_bytes = (sweep ? (size_t)sweep_stat_words(iso_count) * sizeof(uint32_t) : 0u) +
+    const size_t stat_bytes = (sweep ? (size_t)sweep_stat_words(iso_count) * sizeof(uint32_t) : (size_t)kSlotIsoMax * 6u * sizeof(unsigned long long)) +
                               (use_union ? (size_t)8u * kTraceThreads * sizeof(uint32_t) : 0u); /* + the done bits of the union walk */
     const uint32_t top_levels = lds_top_levels(max_depth, view.n_slots, stat_bytes);
     const uint32_t n_top = 1u << top_levels; /* heap positions 0 .. 2^K - 1 = levels 0 .. K-1 (K = 0: the unused slot 0 only) */
@@ -2292,8 +2315,8 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     const uint32_t blocks = (uint32_t)n_cus * kTraceBlocksPerCu;
     const uint64_t frame_pixels = n_pix;
     const uint32_t stack_rows = stack_levels + 1u;
-    /* counters of a short iso range: per-wave slots, summed by a small kernel behind the traversal */
-    WaveStats *slots = !sweep && d_stats && iso_count <= kSlotIsoMax && blocks * (kTraceThreads / 64u) <= kSlotWaveMax ? pp.slots : nullptr;
+    /* counters of a short iso range: summed per block in LDS before they go to the counters */
+    const uint32_t block_counters = !sweep && d_stats && iso_count <= kSlotIsoMax ? 1u : 0u;
     const uint32_t *run_always = nullptr;
     void *args_sweep[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
@@ -2301,7 +2324,7 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                            (void *)&run_always };
     void *args_trace[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
                            (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
-                           (void *)&d_rgb, (void *)&d_stats, (void *)&slots, (void *)&taps };
+                           (void *)&d_rgb, (void *)&d_stats, (void *)&block_counters, (void *)&taps };
     VrUnionRecord *except_list = (VrUnionRecord *)((char *)heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
     uint32_t except_cap = union_except_cap();
     void *args_union[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
@@ -2342,10 +2365,6 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                               (void *)&d_rgb, (void *)&d_stats, (void *)&no_taps, (void *)&redo_ipl, (void *)&redo_seq, (void *)&run_if };
         if ((e = hipLaunchKernel((const void *)vr_k_sweep<false, SweepNarrow>, dim3(blocks), dim3(kTraceThreads), args_redo,
                                  (size_t)redo_top * sizeof(uint32_t) + trace_stack_bytes + redo_stat, stream)) != hipSuccess) return e;
-    }
-    if (slots) {
-        hipLaunchKernelGGL(vr_k_sum_slots, dim3(iso_count), dim3(1024), 0, stream, slots, blocks * (kTraceThreads / 64u), d_stats);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -2434,18 +2453,14 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
     const size_t lds = (size_t)VR_WIDE_MAX_DEPTH * kWideThreads * sizeof(uint32_t);
     const uint32_t blocks = (uint32_t)n_cus * kWideBlocksPerCu;
     const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
-    WaveStats *slots = d_stats && iso_count <= kSlotIsoMax && blocks * (kWideThreads / 64u) <= kSlotWaveMax ? pp.slots : nullptr;
+    const uint32_t block_counters = d_stats && iso_count <= kSlotIsoMax ? 1u : 0u;
     void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&pp.ray_dt, (void *)&pp.ray_pix, (void *)&pp.n_active,
                      (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels, (void *)&d_rgb,
-                     (void *)&d_stats, (void *)&slots, (void *)&taps };
+                     (void *)&d_stats, (void *)&block_counters, (void *)&taps };
     if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
     if ((e = hipLaunchKernel(fn, dim3(blocks), dim3(kWideThreads), args, lds, stream)) != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_end && (e = hipEventRecord(ev_end, stream)) != hipSuccess) return e;
-    if (slots) {
-        hipLaunchKernelGGL(vr_k_sum_slots, dim3(iso_count), dim3(1024), 0, stream, slots, blocks * (kWideThreads / 64u), d_stats);
-        e = hipGetLastError();
-    }
     return e;
 }
 
