@@ -664,6 +664,7 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
             /* Every entry of the table gets a buffer of this size now (at most 8 x 8.1 MiB): a caller whose every call is a new one
              * -- a moving camera -- allocates on its first call and never again, like the rest of the context's scratch. */
             VR_HIP(hipStreamSynchronize(s)); /* an earlier launch may still use a buffer */
+            c->order_flag = nullptr;         /* it points into one of them */
             for (int i = 0; i < vr_ctx::kRemember; i++) {
                 vr_ctx::LptEntry &u = c->lpts[i];
                 if (u.cap >= need) continue;
