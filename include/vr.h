@@ -286,7 +286,8 @@ int vr_selftest(vr_ctx *ctx, uint64_t n_samples, uint64_t mismatches_out[3]);
  * (NULL = the context's own). */
 int vr_trilerp_device(vr_ctx *ctx, const float *d_in, uint64_t n, float *d_out, void *stream);
 
-/* The refinement the reference only sketches: trilerpTrace (src/raytrace.zig:295-304) fetches the hit cell's 8
+/* EXPERIMENTAL: no behaviour of the reference to match (its function is an empty stub); the signature may change.
+ * The refinement the reference only sketches: trilerpTrace (src/raytrace.zig:295-304) fetches the hit cell's 8
  * corner densities (Data.getCornerDens, src/Data.zig:102-114) and stops there.  For every pixel whose ray hit, this
  * post-pass over the taps of vr_render_device (same view, same rows, n_frames frames) evaluates trilerp at the hit
  * point src + dir * t inside the hit cell and stores the interpolated density; 0 for the other pixels.  It is the
