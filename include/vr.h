@@ -374,8 +374,9 @@ typedef struct vr_sweep_info {
     uint32_t items_per_lane; /* the cut of the iso range that launch ran with */
     uint32_t cut_settled;    /* 1 once the context has stopped trying other cuts on this workload */
     uint32_t list_runs;      /* union kernel: runs of iso values that its second kernel had to finish (normally 0) */
-    uint32_t tiles_longest_first; /* union kernel: 1 when the launch repeated the context's previous call and started its tiles of
-                                   * 64 rays in the order of the item lengths that call left (longest first), 0 = list order */
+    uint32_t tiles_longest_first; /* union kernel: 1 when the launch repeated a call the context remembers (one of its last 8) and
+                                   * started its tiles of 64 rays in the order of the item lengths that call left (longest first);
+                                   * 0 = a call it has not seen: the tiles in the order of their rays' chords, or list order */
     uint32_t rendered_again; /* union kernel: 1 when it could not finish the call exactly (more than 32 768 runs of iso values left
                               * its walks, or one front passed 2^20 MOVEs) and the call was rendered again, on the same stream and
                               * before anything the caller enqueued behind it, by the kernel that shares traversals between iso
