@@ -1394,13 +1394,15 @@ __device__ __forceinline__ bool union_front_done(typename UOPS::ULane &U, Store 
     return false;
 }
 
+/* (parameters: what every level of a walk needs first, what only a refill or the end of the launch needs behind it -- the
+ * compiler loads neighbouring arguments as one register tuple and spills and reloads such a tuple whole) */
 template <class UOPS>
 __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
-    VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top, uint32_t stack_rows, const float4 *__restrict__ ray_dt,
-    const uint32_t *__restrict__ ray_pix, const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ head, uint32_t iso_begin,
-    uint32_t iso_count, uint64_t frame_pixels, uint8_t *__restrict__ rgb, vr_render_stats *__restrict__ stats,
+    VrViewK v, const uint32_t *__restrict__ nodes, uint32_t n_top, uint32_t iso_begin, uint32_t iso_count, uint32_t stack_rows,
+    uint8_t *__restrict__ rgb, uint64_t frame_pixels, const float4 *__restrict__ ray_dt, const uint32_t *__restrict__ ray_pix,
+    const uint32_t *__restrict__ n_active_ptr, uint32_t *__restrict__ head, vr_render_stats *__restrict__ stats,
     VrUnionRecord *__restrict__ except_list, uint32_t except_cap, uint32_t items_per_lane, uint32_t launch_seq,
-    const uint32_t *__restrict__ tile_order, uint32_t *__restrict__ tile_cost, uint32_t keep_lengths)
+    uint32_t keep_lengths, const uint32_t *__restrict__ tile_order, uint32_t *__restrict__ tile_cost)
 {
     /* dynamic LDS: [path stacks][check sums and counters as in vr_k_sweep][done bits: 8 x kTraceThreads words][top node words] */
     extern __shared__ uint32_t s_dyn[];
@@ -2327,10 +2329,10 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                            (void *)&d_rgb, (void *)&d_stats, (void *)&block_counters, (void *)&taps };
     VrUnionRecord *except_list = (VrUnionRecord *)((char *)heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
     uint32_t except_cap = union_except_cap();
-    void *args_union[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&stack_rows, (void *)&ray_dt, (void *)&ray_pix,
-                           (void *)&n_active, (void *)&heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
-                           (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
-                           (void *)&launch_seq, (void *)&tile_order, (void *)&tile_cost, (void *)&keep_lengths };
+    void *args_union[] = { (void *)&view, (void *)&d_nodes_prepared, (void *)&n_top, (void *)&iso_begin, (void *)&iso_count, (void *)&stack_rows,
+                           (void *)&d_rgb, (void *)&frame_pixels, (void *)&ray_dt, (void *)&ray_pix, (void *)&n_active, (void *)&heads,
+                           (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
+                           (void *)&launch_seq, (void *)&keep_lengths, (void *)&tile_order, (void *)&tile_cost };
     void **args = use_union ? args_union : (sweep ? args_sweep : args_trace);
     const void *fn = use_union ? (const void *)vr_k_union<UnionNarrow>
                    : sweep ? (any_tap ? (const void *)vr_k_sweep<true, SweepNarrow> : (const void *)vr_k_sweep<false, SweepNarrow>)
@@ -2410,10 +2412,10 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         const uint64_t frame_pixels = (uint64_t)view.width * n_rows;
         VrUnionRecord *except_list = (VrUnionRecord *)((char *)pp.heads + (((size_t)iso_count * sizeof(uint32_t) + 255) & ~(size_t)255));
         uint32_t except_cap = union_except_cap();
-        void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&stack_rows, (void *)&pp.ray_dt, (void *)&pp.ray_pix,
-                         (void *)&pp.n_active, (void *)&pp.heads, (void *)&iso_begin, (void *)&iso_count, (void *)&frame_pixels,
-                         (void *)&d_rgb, (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
-                         (void *)&launch_seq, (void *)&tile_order, (void *)&tile_cost, (void *)&keep_lengths };
+        void *args[] = { (void *)&view, (void *)&d_nodes, (void *)&n_top, (void *)&iso_begin, (void *)&iso_count, (void *)&stack_rows,
+                         (void *)&d_rgb, (void *)&frame_pixels, (void *)&pp.ray_dt, (void *)&pp.ray_pix, (void *)&pp.n_active, (void *)&pp.heads,
+                         (void *)&d_stats, (void *)&except_list, (void *)&except_cap, (void *)&sweep_items_per_lane,
+                         (void *)&launch_seq, (void *)&keep_lengths, (void *)&tile_order, (void *)&tile_cost };
         if (ev_begin && (e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e;
         if ((e = hipLaunchKernel((const void *)vr_k_union<UnionWide>, dim3(blocks), dim3(kTraceThreads), args, lds, stream)) != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
