@@ -470,6 +470,28 @@ def main():
                             "rays_per_step": int(rays_x)}
             del plan
 
+    if world == 1 and not args.no_extras and args.in_flight == 1 and sweep_kernel and not wide and main_plan.rays:
+        # A stream of independent sweeps: two in flight (a second context with its own stream and frame buffer), so that one
+        # sweep's memset and pre-pass and the start of its kernel fall into the other's drain.  Not the headline: `value` is one
+        # sweep after the other on one stream.
+        r2 = vr.Renderer(local_rank)
+        r2.upload_volume(data)
+        r2.build_kdt("AlwaysCenter")
+        r2.set_kernel(args.kernel)
+        two = [slots[0], (r2, torch.empty_like(main_plan.d_rgb), torch.zeros_like(main_plan.d_stats), torch.cuda.Stream())]
+        si2 = capi.SweepInfo()
+        for _ in range(args.settle):  # the second context settles its cut and learns its tile order like the first one did
+            with torch.cuda.stream(two[1][3]):
+                main_plan.render(r2, two[1][1], two[1][2], C.c_void_p(two[1][3].cuda_stream))
+            torch.cuda.synchronize()
+            if L.vr_sweep_info_read(r2.handle, C.byref(si2)) != capi.VR_OK or si2.cut_settled:
+                break
+        dt_x, rays_x, _, _ = measure(main_plan, False, two)
+        extras["two_sweeps_in_flight"] = {"value": rays_x * args.steps / dt_x / 1e6, "unit": "Mrays/s", "ms_per_step": dt_x / args.steps * 1e3,
+                                          "note": "the same step alternating between two contexts, each with its own stream and frames"}
+        del two
+        r2.close()
+
     if rank == 0:
         vol_name = {"skull": "Skull.vol", "c60": "C60.vol", "standin256": "256^3 stand-in", "gyroid1024": "1024^3 gyroid"}[args.volume]
         workload = "%s_%dx%d_iso%d-%d_sweep" % (args.volume, W, H, I0, I0 + IN - 1)

@@ -12,9 +12,9 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 # the cut of the iso range that the library settles on for this workload (an un-profiled run with the usual settling), forced
 # for the profiled runs below so that every traced launch runs with it
-cut=$(timeout -k 10 300 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-delivered --no-first-call --no-latency-floor "$@" 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline'].get('items_per_lane') or '')")
+cut=$(timeout -k 10 300 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-delivered --no-first-call --no-latency-floor --no-extras "$@" 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline'].get('items_per_lane') or '')")
 if [ -n "$cut" ]; then export VR_SWEEP_ITEMS=$cut; echo "settled cut: $cut items per lane"; fi
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 30 --warmup 1 --settle 0 --no-cpu-baseline --no-host-delivered --no-first-call --no-latency-floor "$@" > $out/bench_trace.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 30 --warmup 1 --settle 0 --no-cpu-baseline --no-host-delivered --no-first-call --no-latency-floor --no-extras "$@" > $out/bench_trace.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
 if [ -n "${PROFILE_TRACE_ONLY:-}" ]; then # only the kernel stats again (the counter summary of this workload stays)
   f=$(find $out/trace -name "*kernel_stats.csv" | head -1); w=$(python3 -c "import json; print(json.load(open('$out/bench_trace.json'))['config']['workload'])")
   cp $f $out/r03_stats_$w.csv; echo "$w: kernel stats only"; exit 0
@@ -25,7 +25,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_su
             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum"; do
   i=$((i+1))
-  timeout -s KILL 200 rocprofv3 --pmc $pass --output-format csv -d $out/pmc$i -- python3 $R/bench.py --steps 4 --warmup 1 --settle 0 --no-cpu-baseline --no-host-delivered --no-first-call --no-latency-floor "$@" > $out/pmc$i.json 2> $out/pmc$i.err || { echo "pass $i failed"; tail -3 $out/pmc$i.err; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc $pass --output-format csv -d $out/pmc$i -- python3 $R/bench.py --steps 4 --warmup 1 --settle 0 --no-cpu-baseline --no-host-delivered --no-first-call --no-latency-floor --no-extras "$@" > $out/pmc$i.json 2> $out/pmc$i.err || { echo "pass $i failed"; tail -3 $out/pmc$i.err; exit 1; }
 done
 python3 - "$out" "$commit" "$R" <<'PY'
 import csv, glob, collections, json, re, sys, hashlib, os, shutil
