@@ -439,7 +439,7 @@ extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8
             const CountingFetch fetch{ nodes, &n_reads, (uint32_t)(n_slots - 1u) & ~1u };
             for (;;) {
                 while (U.alive_lo <= U.alive_hi) {
-                    const uint32_t go = vr_union_descend(U, fetch, st, done, sink, max_trips);
+                    const uint32_t go = vr_union_descend<true>(U, fetch, st, done, sink, max_trips);
                     if (go == VR_GO_MORE) continue;
                     if (U.alive_lo > U.alive_hi) break;
                     n_states++;
@@ -575,7 +575,7 @@ extern "C" int vr_emu_union_wide(const uint32_t *nodes, uint64_t n_slots, const 
             const CountingFetch fetch{ nodes, &n_reads, 0u };
             for (;;) {
                 while (U.alive_lo <= U.alive_hi) {
-                    const uint32_t go = vr_uw_descend(U, fetch, path, done, sink, max_trips);
+                    const uint32_t go = vr_uw_descend<true>(U, fetch, path, done, sink, max_trips);
                     if (go == VR_GO_MORE) continue;
                     if (U.alive_lo > U.alive_hi) break;
                     n_states++;

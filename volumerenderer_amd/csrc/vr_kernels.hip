@@ -1328,8 +1328,13 @@ struct UnionNarrow {
     __device__ static __forceinline__ void begin(ULane &U, Store &st, Done &done, const VrViewK &v, const float4 &r, uint32_t b, uint32_t n) { vr_union_begin(U, st, done, v, r.x, r.y, r.z, r.w, b, n); }
     template <class Done>
     __device__ static __forceinline__ void restart(ULane &U, Store &st, Done &done, const VrViewK &v, float t, uint32_t cell, const VrUnionRuns &runs) { vr_union_restart(U, st, done, v, t, cell, runs); }
+    /* the lanes of a wave that go down together take the loop without the done bits when none of them has a hole in its alive range */
     template <class Done, class Sink>
-    __device__ static __forceinline__ uint32_t descend(ULane &U, const Fetch &f, Store &st, Done &done, Sink &sink) { return vr_union_descend(U, f, st, done, sink, kUnionDescendTrips); }
+    __device__ static __forceinline__ uint32_t descend(ULane &U, const Fetch &f, Store &st, Done &done, Sink &sink)
+    {
+        if (__ballot(U.holes) == 0ull) return vr_union_descend<false>(U, f, st, done, sink, kUnionDescendTrips);
+        return vr_union_descend<true>(U, f, st, done, sink, kUnionDescendTrips);
+    }
     __device__ static __forceinline__ uint32_t depth(const ULane &, const Store &st) { return st.depth(); }
     __device__ static __forceinline__ uint32_t cell(const ULane &U) { return U.L.cell; }
     __device__ static __forceinline__ Exit move(ULane &U, const VrViewK &v) { return vr_union_move(U.L, v); }
@@ -1359,7 +1364,11 @@ struct UnionWide {
     template <class Done>
     __device__ static __forceinline__ void restart(ULane &U, Store &, Done &done, const VrViewK &v, float t, uint32_t cell, const VrUnionRuns &runs) { vr_uw_restart(U, done, v, t, cell, runs); }
     template <class Done, class Sink>
-    __device__ static __forceinline__ uint32_t descend(ULane &U, const Fetch &f, Store &st, Done &done, Sink &sink) { return vr_uw_descend(U, f, st, done, sink, kUnionDescendTrips); }
+    __device__ static __forceinline__ uint32_t descend(ULane &U, const Fetch &f, Store &st, Done &done, Sink &sink)
+    {
+        if (__ballot(U.holes) == 0ull) return vr_uw_descend<false>(U, f, st, done, sink, kUnionDescendTrips);
+        return vr_uw_descend<true>(U, f, st, done, sink, kUnionDescendTrips);
+    }
     __device__ static __forceinline__ uint32_t depth(const ULane &U, const Store &) { return U.L.d; }
     __device__ static __forceinline__ uint32_t cell(const ULane &U) { return U.L.c; }
     __device__ static __forceinline__ Exit move(ULane &U, const VrViewK &v) { return vr_uw_move(U.L, v); }

@@ -105,10 +105,10 @@ VR_HD void vr_union_mark(Done &done, uint32_t r0, uint32_t r1)
 
 /* is any iso value in [mn, mx] not done? */
 template <class Done, class ULane>
-VR_HD bool vr_union_any(const Done &done, const ULane &U, uint32_t mn, uint32_t mx)
+VR_HD bool vr_union_any(const Done &done, const ULane &U, uint32_t mn, uint32_t mx, bool holes)
 {
     if (U.alive_lo > U.alive_hi || mx < U.alive_lo || mn > U.alive_hi) return false;
-    if (!U.holes || (mn <= U.alive_lo && U.alive_lo <= mx) || (mn <= U.alive_hi && U.alive_hi <= mx)) return true;
+    if (!holes || (mn <= U.alive_lo && U.alive_lo <= mx) || (mn <= U.alive_hi && U.alive_hi <= mx)) return true;
     /* strictly inside (alive_lo, alive_hi) here: the bits are valid */
     for (uint32_t w = mn >> 5; w <= (mx >> 5); w++) {
         VR_WC(4);
@@ -204,10 +204,13 @@ VR_HD void vr_union_restart(VrUnionLane &U, Stack &stack, Done &done, const VrVi
 /* Goes down from the current node while an iso value that is not done holds, at most max_trips levels.  Returns
  * VR_GO_MORE (budget used up) or VR_GO_EXCLUDED (nobody goes into the current node, or it was a leaf and its iso
  * values have hit: the front leaves its box next). */
-template <class Fetch, class Stack, class Done, class Sink>
+/* HOLES = false: the caller knows that no lane that goes down here has a done iso value inside its alive range (U.holes is
+ * false for all of them), which is the rule: the code that goes through the done bits is then left out of the loop. */
+template <bool HOLES, class Fetch, class Stack, class Done, class Sink>
 VR_HD uint32_t vr_union_descend(VrUnionLane &U, const Fetch &fetch, Stack &stack, Done &done, Sink &sink, uint32_t max_trips)
 {
     VrLane &L = U.L;
+    const bool holes = HOLES ? U.holes : false; /* stays as it is until a leaf ends the descent */
     VR_ROLLED
     for (uint32_t trip = 0; trip < max_trips; trip++) {
         const uint32_t n = fetch(L.g);
@@ -217,18 +220,18 @@ VR_HD uint32_t vr_union_descend(VrUnionLane &U, const Fetch &fetch, Stack &stack
         /* present: the parent's range; excluded here: what this node's range leaves out on either side */
         if (mn > U.prev_mn) {
             const uint32_t p = U.prev_mn > U.alive_lo ? U.prev_mn : U.alive_lo, q = mn - 1u < U.alive_hi ? mn - 1u : U.alive_hi;
-            if (p <= q) { VR_WC(1); vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes); }
+            if (p <= q) { VR_WC(1); vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, holes); }
         }
         if (mx < U.prev_mx) {
             const uint32_t p = mx + 1u > U.alive_lo ? mx + 1u : U.alive_lo, q = U.prev_mx < U.alive_hi ? U.prev_mx : U.alive_hi;
-            if (p <= q) { VR_WC(2); vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes); }
+            if (p <= q) { VR_WC(2); vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, holes); }
         }
-        if (!vr_union_any(done, U, mn, mx)) return VR_GO_EXCLUDED;
+        if (!vr_union_any(done, U, mn, mx, holes)) return VR_GO_EXCLUDED;
         if (n & VR_N_LEAF) {
             VR_WC(5);
             const uint32_t p = mn > U.alive_lo ? mn : U.alive_lo, q = mx < U.alive_hi ? mx : U.alive_hi;
-            vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.hit(r0, r1, checks, L.t, L.cell, L.g); }, U.holes);
-            if (!U.holes && (p == U.alive_lo || q == U.alive_hi)) { /* hits off either end leave no hole */
+            vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.hit(r0, r1, checks, L.t, L.cell, L.g); }, holes);
+            if (!holes && (p == U.alive_lo || q == U.alive_hi)) { /* hits off either end leave no hole */
                 if (p == U.alive_lo) U.alive_lo = q + 1u; /* past alive_hi when both ends went: none left */
                 else U.alive_hi = p - 1u;
             } else {

@@ -38,11 +38,12 @@ VR_HD void vr_uw_restart(VrUnionWideLane &U, Done &done, const VrViewK &v, float
     vr_union_set_runs(U, done, runs);
 }
 
-/* vr_union_descend on a wide tree */
-template <class Fetch, class Path, class Done, class Sink>
+/* vr_union_descend on a wide tree (HOLES as there) */
+template <bool HOLES, class Fetch, class Path, class Done, class Sink>
 VR_HD uint32_t vr_uw_descend(VrUnionWideLane &U, const Fetch &fetch, Path &path, Done &done, Sink &sink, uint32_t max_trips)
 {
     VrWideLane &L = U.L;
+    const bool holes = HOLES ? U.holes : false;
     VR_ROLLED
     for (uint32_t trip = 0; trip < max_trips; trip++) {
         const uint32_t n = fetch(L.idx);
@@ -50,17 +51,17 @@ VR_HD uint32_t vr_uw_descend(VrUnionWideLane &U, const Fetch &fetch, Path &path,
         const uint32_t checks = L.d + 1u; /* root .. this node (src/raytrace.zig:162) */
         if (mn > U.prev_mn) {
             const uint32_t p = U.prev_mn > U.alive_lo ? U.prev_mn : U.alive_lo, q = mn - 1u < U.alive_hi ? mn - 1u : U.alive_hi;
-            if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes);
+            if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, holes);
         }
         if (mx < U.prev_mx) {
             const uint32_t p = mx + 1u > U.alive_lo ? mx + 1u : U.alive_lo, q = U.prev_mx < U.alive_hi ? U.prev_mx : U.alive_hi;
-            if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, U.holes);
+            if (p <= q) vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.park(r0, r1, checks); }, holes);
         }
-        if (!vr_union_any(done, U, mn, mx)) return VR_GO_EXCLUDED;
+        if (!vr_union_any(done, U, mn, mx, holes)) return VR_GO_EXCLUDED;
         if (L.hi - L.lo == VR_F_ONES) { /* a box of size 1 is a leaf: every present iso value in its range hits here */
             const uint32_t p = mn > U.alive_lo ? mn : U.alive_lo, q = mx < U.alive_hi ? mx : U.alive_hi;
-            vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.hit(r0, r1, checks, L.t, L.c, L.idx); }, U.holes);
-            if (!U.holes && (p == U.alive_lo || q == U.alive_hi)) {
+            vr_union_runs(done, p, q, [&](uint32_t r0, uint32_t r1) { sink.hit(r0, r1, checks, L.t, L.c, L.idx); }, holes);
+            if (!holes && (p == U.alive_lo || q == U.alive_hi)) {
                 if (p == U.alive_lo) U.alive_lo = q + 1u;
                 else U.alive_hi = p - 1u;
             } else {
