@@ -448,7 +448,7 @@ extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8
                     bool suspect = false;
                     if (!x.in_root) {
                         const float t_new = U.L.t;
-                        vr_union_leave(U.L, st, x, suspect);
+                        vr_union_leave(U.L, st, x, suspect, k.root_hi);
                         if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false, VrUnionFrom{ 1u, 0u, k.root_hi }); }
                         else vr_union_credit_esc(done, U, sink, 0u, 255u, x.esc);
                         if (U.alive_lo <= U.alive_hi)
@@ -584,7 +584,7 @@ extern "C" int vr_emu_union_wide(const uint32_t *nodes, uint64_t n_slots, const 
                     bool suspect = false;
                     if (!x.in_root) {
                         const float t_new = U.L.t;
-                        vr_uw_leave(U.L, path, x, suspect);
+                        vr_uw_leave(U.L, path, x, suspect, vr_pack10(k.rdx, k.rdy, k.rdz));
                         if (suspect) { n_suspect++; vr_uw_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false, VrUnionFrom{ 0u, 0u, vr_pack10(k.rdx, k.rdy, k.rdz) }); }
                         else vr_union_credit_esc(done, U, sink, 0u, 255u, x.esc);
                         if (U.alive_lo <= U.alive_hi)

@@ -1349,7 +1349,7 @@ struct UnionNarrow {
     __device__ static __forceinline__ Exit move(ULane &U, const VrViewK &v) { return vr_union_move(U.L, v); }
     __device__ static __forceinline__ bool pop(ULane &U, Store &st, const Exit &x, bool &suspect, VrUnionFrom &from) { return vr_union_pop(U.L, st, kUnionPopTrips, x, suspect, from); }
     __device__ static __forceinline__ VrUnionFrom root(const VrViewK &v) { return VrUnionFrom{ 1u, 0u, v.root_hi }; }
-    __device__ static __forceinline__ void leave(ULane &U, Store &st, const Exit &x, bool &suspect) { vr_union_leave(U.L, st, x, suspect); }
+    __device__ static __forceinline__ void leave(ULane &U, Store &st, const Exit &x, bool &suspect, const VrViewK &v) { vr_union_leave(U.L, st, x, suspect, v.root_hi); }
     template <class Done, class Sink>
     __device__ static __forceinline__ void resolve(ULane &U, const VrViewK &v, const Fetch &f, Done &done, Sink &sink, uint32_t depth_k,
                                                    uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root,
@@ -1383,7 +1383,7 @@ struct UnionWide {
     __device__ static __forceinline__ Exit move(ULane &U, const VrViewK &v) { return vr_uw_move(U.L, v); }
     __device__ static __forceinline__ bool pop(ULane &U, Store &st, const Exit &x, bool &suspect, VrUnionFrom &from) { return vr_uw_pop(U.L, st, kUnionPopTrips, x, suspect, from); }
     __device__ static __forceinline__ VrUnionFrom root(const VrViewK &v) { return VrUnionFrom{ 0u, 0u, vr_pack10(v.rdx, v.rdy, v.rdz) }; }
-    __device__ static __forceinline__ void leave(ULane &U, Store &st, const Exit &x, bool &suspect) { vr_uw_leave(U.L, st, x, suspect); }
+    __device__ static __forceinline__ void leave(ULane &U, Store &st, const Exit &x, bool &suspect, const VrViewK &v) { vr_uw_leave(U.L, st, x, suspect, vr_pack10(v.rdx, v.rdy, v.rdz)); }
     template <class Done, class Sink>
     __device__ static __forceinline__ void resolve(ULane &U, const VrViewK &v, const Fetch &f, Done &done, Sink &sink, uint32_t depth_k,
                                                    uint32_t cell_before, int a_level, float t_new, uint32_t cell_new, bool in_root,
@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     } else if (!x.in_root) {
                         /* the front has left the volume: what is not done is a miss (src/raytrace.zig:66-68) */
                         const float t_new = U.L.t;
-                        UOPS::leave(U, stack, x, suspect);
+                        UOPS::leave(U, stack, x, suspect, v);
                         if (suspect) UOPS::resolve(U, v, fetch, done, sink, depth_k, cell_before, -1, t_new, 0u, false, UOPS::root(v));
                         else vr_union_credit_esc(done, U, sink, 0u, 255u, x.esc);
                         if (U.alive_lo <= U.alive_hi)

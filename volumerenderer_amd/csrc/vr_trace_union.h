@@ -365,10 +365,14 @@ VR_HD bool vr_union_pop(VrLane &L, Stack &stack, uint32_t max_trips, const VrUni
 }
 
 /* The front has left the root box: every level of the path is left.  Sets `suspect` if any box on the way up does not
- * share the front's exit plane. */
+ * share the front's exit plane.  Along an axis the exit plane of a box lies between its child's and its parent's, so when
+ * the root's own exit plane (root_hi: the root box's upper corner) is the front's on an axis that gave the front's t --
+ * the rule: a ray leaves the volume through the face its last box touches -- every box in between has it too and the walk
+ * up is left out (the path store keeps its levels; the next front starts it afresh). */
 template <class Stack>
-VR_HD void vr_union_leave(VrLane &L, Stack &stack, const VrUnionExit &x, bool &suspect)
+VR_HD void vr_union_leave(VrLane &L, Stack &stack, const VrUnionExit &x, bool &suspect, uint32_t root_hi)
 {
+    if (vr_union_same_exit(root_hi & L.posmask, x.ex, x.tied)) return;
     while (stack.depth() > 0u) {
         VR_WC(9);
         const uint32_t word = stack.peek_up(1); /* the top entry: the bound the last split replaced */

@@ -158,10 +158,11 @@ VR_HD bool vr_uw_pop(VrWideLane &L, Path &path, uint32_t max_trips, const VrUnio
     return true;
 }
 
-/* the front has left the root box: every level of the path is left */
+/* the front has left the root box: every level of the path is left (vr_union_leave; root_hi = the root box's upper corner) */
 template <class Path>
-VR_HD void vr_uw_leave(VrWideLane &L, Path &path, const VrUnionWideExit &x, bool &suspect)
+VR_HD void vr_uw_leave(VrWideLane &L, Path &path, const VrUnionWideExit &x, bool &suspect, uint32_t root_hi)
 {
+    if (vr_union_same_exit(root_hi & x.pm, x.ex, x.tied)) return;
     uint32_t lo = L.lo, hi = L.hi;
     for (uint32_t k = L.d; k > 0u;) {
         k--;
