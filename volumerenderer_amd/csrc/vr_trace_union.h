@@ -346,12 +346,14 @@ VR_HD bool vr_union_pop(VrLane &L, Stack &stack, uint32_t max_trips, const VrUni
         found = ((a & b) & VR_F_GUARD) == VR_F_GUARD;
         if (found) break;
         /* the parent's box is left as well: the iso values parked there make their own MOVE out of it */
-        const uint32_t ex_a = (a_hi & L.posmask) | (a_lo & ~L.posmask);
-        suspect = suspect || !vr_union_same_exit(ex_a, x.ex, x.tied);
         L.lo = a_lo; L.hi = a_hi;
         L.g >>= 1;
     }
     if (!found) return false;
+    /* Every box that was left must share the front's exit plane.  Along an axis the exit plane of a box lies between its
+     * child's and its parent's, so the largest box left -- the one the lane stands on now, a child of the ancestor that holds
+     * the point -- decides for all the boxes below it. */
+    suspect = suspect || !vr_union_same_exit((L.hi & L.posmask) | (L.lo & ~L.posmask), x.ex, x.tied);
     from.node = L.g >> 1; from.lo = a_lo; from.hi = a_hi; /* the ancestor that holds the new point */
     const uint32_t cut = left ? L.hi : L.lo, keep = left ? L.lo : L.hi;
     const uint32_t carry = ((word ^ cut) + 0xffu * VR_F_ONES) & VR_F_GUARD;
@@ -365,25 +367,15 @@ VR_HD bool vr_union_pop(VrLane &L, Stack &stack, uint32_t max_trips, const VrUni
 }
 
 /* The front has left the root box: every level of the path is left.  Sets `suspect` if any box on the way up does not
- * share the front's exit plane.  Along an axis the exit plane of a box lies between its child's and its parent's, so when
- * the root's own exit plane (root_hi: the root box's upper corner) is the front's on an axis that gave the front's t --
- * the rule: a ray leaves the volume through the face its last box touches -- every box in between has it too and the walk
- * up is left out (the path store keeps its levels; the next front starts it afresh). */
+ * share the front's exit plane.  Along an axis the exit plane of a box lies between its child's and its parent's, so the
+ * root box (root_hi: its upper corner) decides for every box below it, and nothing is walked (the path store keeps its
+ * levels; the next front starts it afresh).  The rule is "not suspect": a ray leaves the volume through the face its last
+ * box touches. */
 template <class Stack>
 VR_HD void vr_union_leave(VrLane &L, Stack &stack, const VrUnionExit &x, bool &suspect, uint32_t root_hi)
 {
-    if (vr_union_same_exit(root_hi & L.posmask, x.ex, x.tied)) return;
-    while (stack.depth() > 0u) {
-        VR_WC(9);
-        const uint32_t word = stack.peek_up(1); /* the top entry: the bound the last split replaced */
-        stack.up();
-        const bool left = (L.g & 1u) == 0u;
-        const uint32_t a_lo = left ? L.lo : word, a_hi = left ? word : L.hi;
-        const uint32_t ex_a = (a_hi & L.posmask) | (a_lo & ~L.posmask);
-        suspect = suspect || !vr_union_same_exit(ex_a, x.ex, x.tied);
-        L.lo = a_lo; L.hi = a_hi;
-        L.g >>= 1;
-    }
+    (void)stack;
+    suspect = suspect || !vr_union_same_exit(root_hi & L.posmask, x.ex, x.tied);
 }
 
 /* Exact resolution of a suspect MOVE.  The front stood on the node at heap position g_k (level depth_k) with point

@@ -130,6 +130,7 @@ template <class Path>
 VR_HD bool vr_uw_pop(VrWideLane &L, Path &path, uint32_t max_trips, const VrUnionWideExit &x, bool &suspect, VrUnionFrom &from)
 {
     uint32_t lo = L.lo, hi = L.hi, in3 = L.in3, k = L.k, e = 0;
+    uint32_t left_lo = lo, left_hi = hi; /* the largest box left so far: it decides for all the boxes inside it (vr_union_pop) */
     const uint32_t c = L.c;
     for (uint32_t trip = 0; in3 != 7u && k > 0u; trip++) {
         if (trip == max_trips) {
@@ -146,8 +147,9 @@ VR_HD bool vr_uw_pop(VrWideLane &L, Path &path, uint32_t max_trips, const VrUnio
         const uint32_t ok = vr_wide_field(lo, sh) <= ca && ca < vr_wide_field(hi, sh) ? 1u : 0u;
         in3 = (in3 & ~(1u << axis)) | (ok << axis);
         /* the box of level k is left as well: the iso values parked there make their own MOVE out of it */
-        if (in3 != 7u) suspect = suspect || !vr_union_same_exit((hi & x.pm) | (lo & ~x.pm), x.ex, x.tied);
+        if (in3 != 7u) { left_lo = lo; left_hi = hi; }
     }
+    suspect = suspect || !vr_union_same_exit((left_hi & x.pm) | (left_lo & ~x.pm), x.ex, x.tied);
     L.lo = lo; L.hi = hi;
     if (k < L.d) {
         L.idx = ((L.idx + 1u) >> (L.d - k)) - 1u;
@@ -162,17 +164,8 @@ VR_HD bool vr_uw_pop(VrWideLane &L, Path &path, uint32_t max_trips, const VrUnio
 template <class Path>
 VR_HD void vr_uw_leave(VrWideLane &L, Path &path, const VrUnionWideExit &x, bool &suspect, uint32_t root_hi)
 {
-    if (vr_union_same_exit(root_hi & x.pm, x.ex, x.tied)) return;
-    uint32_t lo = L.lo, hi = L.hi;
-    for (uint32_t k = L.d; k > 0u;) {
-        k--;
-        const uint32_t e = path.get(k);
-        const uint32_t sh = (e >> 12) & 31u, old = (e >> 18) & 0x3ffu;
-        const uint32_t keep = ~(0x3ffu << sh), put = old << sh;
-        if (e & (1u << 17)) lo = (lo & keep) | put;
-        else hi = (hi & keep) | put;
-        suspect = suspect || !vr_union_same_exit((hi & x.pm) | (lo & ~x.pm), x.ex, x.tied);
-    }
+    (void)L; (void)path;
+    suspect = suspect || !vr_union_same_exit(root_hi & x.pm, x.ex, x.tied);
 }
 
 template <class Fetch>
