@@ -49,7 +49,7 @@ constexpr uint32_t kRefillMin = VR_REFILL_MIN; /* refill a wave once this many l
 #define VR_DESCEND_TRIPS 6
 #endif
 #ifndef VR_POP_TRIPS
-#define VR_POP_TRIPS 6
+#define VR_POP_TRIPS 8 /* (frames of Skull 1024^2 / C60 1024^2 / Skull 4096^2, kernel ms: 6: 0.303 / 0.147 / 0.953, 8: 0.296 / 0.147 / 0.943, 10: 0.302 / 0.155 / 0.966) */
 #endif
 /* levels a lane may descend / pop per round before the wave moves on; unfinished lanes continue next round */
 constexpr uint32_t kDescendTrips = VR_DESCEND_TRIPS, kPopTrips = VR_POP_TRIPS;
