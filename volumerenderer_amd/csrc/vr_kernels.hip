@@ -1195,7 +1195,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
 #define VR_UNION_DESCEND_TRIPS 5
 #endif
 #ifndef VR_UNION_POP_TRIPS
-#define VR_UNION_POP_TRIPS 9 /* levels up per round (Skull sweep: 1.124 ms with 5, 1.085 with 7, 1.056 with 9 or 11, 1.07 with 13 or 16) */
+#define VR_UNION_POP_TRIPS 11 /* levels up per round (Skull sweep, with one exit-plane check per pop: 1.000 ms with 9, 0.986 with 11, 0.990 with 13;
+                               * C60 0.733 / 0.724 with 9 / 11, 256^3 stand-in 2.51 / 2.49) */
 #endif
 #ifndef VR_UNION_REFILL_MIN
 #define VR_UNION_REFILL_MIN 24 /* idle lanes from which a wave takes new items (Skull / C60 / stand-in sweep, ms: 16: 1.048 / 0.788 / 2.71,
