@@ -3,6 +3,7 @@
  * is built without VR_MEASURE: every macro below is then empty and nothing of this file reaches the code object.
  *
  *   tools/tune_build.sh items -DVR_MEASURE -DVR_SWEEP_MAX_BLOCKS=256     ->  volumerenderer_amd/tune/libvr_items.so
+ *   (add -DVR_MEASURE_COUNTS for the wave-level execution counts, in a build of their own: libvr_counts.so)
  *
  * What it records, for vr_k_union<UnionNarrow / UnionWide> launches through vr_launch_render:
  *   - per (ray, block of iso values) item: rounds and ticks of the 100 MHz clock from its start to the end of its last front,
@@ -36,8 +37,14 @@ __device__ uint32_t g_trace_n;
 __device__ uint32_t g_trace[2 * 4096]; /* per round: tick since the launch began, fronts in the wave | descending << 8 | popping << 16 | round << 20 */
 __device__ unsigned long long g_wave_counts[24];
 
-/* one count per wave that runs through here, whatever the number of its lanes that do */
+/* one count per wave that runs through here, whatever the number of its lanes that do.  Only with -DVR_MEASURE_COUNTS as well: the
+ * counts are device-wide atomics on two dozen words and make a launch a hundred times longer, so the item tables and the round
+ * trace of a build that has them say nothing about time. */
+#ifdef VR_MEASURE_COUNTS
 #define VR_WC(i) do { const unsigned long long e__ = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)e__) - 1u) atomicAdd(&g_wave_counts[i], 1ull); } while (0)
+#else
+#define VR_WC(i) do { } while (0)
+#endif
 
 /* per-lane state of the item a lane works on */
 struct VrMeasureLane {
