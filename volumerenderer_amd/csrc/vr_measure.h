@@ -36,11 +36,15 @@ __device__ uint32_t g_trace_slot = 0xffffffffu;      /* the item whose rounds ar
 __device__ uint32_t g_trace_n;
 __device__ uint32_t g_trace[2 * 4096]; /* per round: tick since the launch began, fronts in the wave | descending << 8 | popping << 16 | round << 20 */
 __device__ unsigned long long g_wave_counts[24];
+__device__ uint32_t g_trace_wave = 0xffffffffu;      /* block * 16 + wave of the wave that took the traced item */
 
 /* one count per wave that runs through here, whatever the number of its lanes that do.  Only with -DVR_MEASURE_COUNTS as well: the
  * counts are device-wide atomics on two dozen words and make a launch a hundred times longer, so the item tables and the round
  * trace of a build that has them say nothing about time. */
-#ifdef VR_MEASURE_COUNTS
+#if defined(VR_MEASURE_COUNTS) && VR_MEASURE_COUNTS == 2
+/* ... = 2: only the wave that holds the traced item counts (from the moment it takes the item): what ONE wave runs through */
+#define VR_WC(i) do { if (blockIdx.x * 16u + (threadIdx.x >> 6) == *(volatile uint32_t *)&g_trace_wave) { const unsigned long long e__ = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)e__) - 1u) atomicAdd(&g_wave_counts[i], 1ull); } } while (0)
+#elif defined(VR_MEASURE_COUNTS)
 #define VR_WC(i) do { const unsigned long long e__ = __ballot(1); if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)e__) - 1u) atomicAdd(&g_wave_counts[i], 1ull); } while (0)
 #else
 #define VR_WC(i) do { } while (0)
@@ -53,6 +57,7 @@ struct VrMeasureLane {
     {
         slot = item_slot; t0 = (uint32_t)__builtin_amdgcn_s_memrealtime(); rounds = 0;
         if (slot < kMeasureItemsCap) g_item_begin[slot] = t0 - (uint32_t)tick_begin + 1u;
+        if (slot == g_trace_slot) g_trace_wave = blockIdx.x * 16u + (threadIdx.x >> 6);
     }
     __device__ __forceinline__ void end() const
     {
@@ -102,6 +107,8 @@ static inline void vr_measure_before_launch(hipStream_t stream)
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_slot), &slot, 4);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, 4);
+        const uint32_t none = 0xffffffffu;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_wave), &none, 4);
     }
 }
 
