@@ -395,13 +395,38 @@ struct HostUnionSink {
 };
 } // namespace
 
+/* What the lane code's `suspect` stands for, level by level (test only): does any box the point has left -- every ancestor up
+ * to, not including, the first one that holds the new point; all of them when the front has left the volume -- not share the
+ * front's exit plane?  The lane code decides it from the largest box left alone. */
+static bool emu_suspect_by_levels(VrLane L, HostStack st, const VrUnionExit &x, bool leaving)
+{
+    bool suspect = false;
+    const uint32_t cg = L.cell | VR_F_GUARD, cp = L.cell + VR_F_ONES;
+    while (st.depth() > 0u) {
+        const uint32_t word = st.peek_up(1);
+        st.up();
+        const bool left = (L.g & 1u) == 0u;
+        const uint32_t a_lo = left ? L.lo : word, a_hi = left ? word : L.hi;
+        if (!leaving) {
+            const uint32_t a = cg - a_lo, b = (a_hi | VR_F_GUARD) - cp;
+            if (((a & b) & VR_F_GUARD) == VR_F_GUARD) break;
+        }
+        suspect = suspect || !vr_union_same_exit((a_hi & L.posmask) | (a_lo & ~L.posmask), x.ex, x.tied);
+        L.lo = a_lo; L.hi = a_hi;
+        L.g >>= 1;
+    }
+    return suspect;
+}
+
 /* counts_out: [0] node reads of the descents, [1] states (MOVEs of the front), [2] suspect MOVEs resolved exactly,
- * [3] runs of iso values that left the union walk, [4] iso values in them */
+ * [3] runs of iso values that left the union walk, [4] iso values in them, [5] MOVEs whose `suspect` differs from the
+ * level-by-level definition (emu_suspect_by_levels) */
 extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8_t root_dim[3], const float src[3],
                             const float forw[3], const float up[3], uint32_t width, uint32_t height, float viewport_width,
                             uint32_t iso_begin, uint32_t iso_count, uint32_t max_trips, uint8_t *gray, uint32_t *cell_flag,
-                            float *t_out, uint32_t *node, uint64_t *sums /*[iso_count][7]*/, uint64_t *counts_out /*[5]*/)
+                            float *t_out, uint32_t *node, uint64_t *sums /*[iso_count][7]*/, uint64_t *counts_out /*[6]*/)
 {
+    uint64_t n_suspect_differs = 0;
     VrViewK k;
     k.ox = src[0]; k.oy = src[1]; k.oz = src[2];
     k.fx = forw[0]; k.fy = forw[1]; k.fz = forw[2];
@@ -448,7 +473,9 @@ extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8
                     bool suspect = false;
                     if (!x.in_root) {
                         const float t_new = U.L.t;
+                        const bool by_levels = emu_suspect_by_levels(U.L, st, x, true);
                         vr_union_leave(U.L, st, x, suspect, k.root_hi);
+                        n_suspect_differs += suspect != by_levels;
                         if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, -1, t_new, 0u, false, VrUnionFrom{ 1u, 0u, k.root_hi }); }
                         else vr_union_credit_esc(done, U, sink, 0u, 255u, x.esc);
                         if (U.alive_lo <= U.alive_hi)
@@ -456,7 +483,9 @@ extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8
                         break;
                     }
                     VrUnionFrom from = { 1u, 0u, k.root_hi };
+                    const bool by_levels = emu_suspect_by_levels(U.L, st, x, false);
                     while (!vr_union_pop(U.L, st, max_trips, x, suspect, from)) {}
+                    n_suspect_differs += suspect != by_levels;
                     if (suspect) { n_suspect++; vr_union_resolve(U, k, HostFetch{ nodes }, done, sink, depth_k, cell_before, (int)st.depth() - 1, U.L.t, U.L.cell, true, from); }
                     const bool credit = !suspect;
                     vr_union_after_pop(U, HostFetch{ nodes });
@@ -468,7 +497,7 @@ extern "C" int vr_emu_union(const uint32_t *nodes, uint64_t n_slots, const uint8
             }
             n_except += sink.n_except; n_except_isos += sink.n_except_isos;
         }
-    if (counts_out) { counts_out[0] = n_reads; counts_out[1] = n_states; counts_out[2] = n_suspect; counts_out[3] = n_except; counts_out[4] = n_except_isos; }
+    if (counts_out) { counts_out[0] = n_reads; counts_out[1] = n_states; counts_out[2] = n_suspect; counts_out[3] = n_except; counts_out[4] = n_except_isos; counts_out[5] = n_suspect_differs; }
     return 0;
 }
 

@@ -92,7 +92,7 @@ def emu_union(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, max_trips
     tt = np.zeros((iso_count, h, w), np.float32)
     nd = np.zeros((iso_count, h, w), np.uint32)
     sums = np.zeros((iso_count, 7), np.uint64)
-    counts = np.zeros(5, np.uint64)
+    counts = np.zeros(6, np.uint64)
     f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
     prep = np.ascontiguousarray(prep, dtype=np.uint32)
     L.vr_emu_union(C.c_void_p(prep.ctypes.data), C.c_uint64(n_slots), (C.c_uint8 * 3)(*[int(x) for x in rd]), f3(pos),
@@ -100,7 +100,7 @@ def emu_union(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, max_trips
                    C.c_uint32(max_trips), C.c_void_p(gray.ctypes.data), C.c_void_p(cf.ctypes.data), C.c_void_p(tt.ctypes.data),
                    C.c_void_p(nd.ctypes.data), C.c_void_p(sums.ctypes.data), C.c_void_p(counts.ctypes.data))
     return {"gray": gray, "cell_flag": cf, "t": tt, "node": nd, "sums": sums, "node_reads": int(counts[0]),
-            "states": int(counts[1]), "suspect": int(counts[2]), "left_runs": int(counts[3]), "left_isos": int(counts[4])}
+            "states": int(counts[1]), "suspect": int(counts[2]), "left_runs": int(counts[3]), "left_isos": int(counts[4]), "suspect_differs": int(counts[5])}
 
 
 def emu_union_wide(L, nodes, rd, pos, f, u, w, h, vp, iso_begin, iso_count, max_trips=5):

@@ -156,3 +156,26 @@ def test_union_walk_on_noise_partial_ranges_and_close_cameras(oracle, emu_lib):
             for b, n in [(0, 256), (17, 100), (255, 1), (200, 56)]:
                 got = emu_union(emu_lib, nodes, rd, pos, forw, up, 24, 16, vp, b, n, max_trips=3)
                 _check_union(oracle, got, nodes, rd, pos, forw, up, 24, 16, vp, b, n, step=1 if n <= 100 else 3)
+
+
+def test_union_walk_suspect_is_decided_by_the_largest_box_left(oracle, emu_lib, c60_vox, c60_tree, skull_vox, skull_tree):
+    """A MOVE is suspect when a box the point has left does not share the front's exit plane.  The lane code asks the largest
+    box left only (the exit plane of a box lies between its child's and its parent's along every axis); the emulator works the
+    same question out level by level for every MOVE and counts the differences: none, on walks that do have suspect MOVEs."""
+    from helpers import emu_union
+    rng = np.random.default_rng(5)
+    cases = [(c60_vox, c60_tree, 64, 48, 0, 256, None), (skull_vox, skull_tree, 96, 80, 0, 256, None),
+             (None, None, 40, 32, 0, 256, (20, 17, 23)), (None, None, 40, 32, 90, 60, (16, 16, 16))]
+    cases.append((None, None, 48, 40, 0, 256, (24, 24, 24)))
+    n_suspect = n_states = 0
+    for vox, tree, W, H, b, n, shape in cases:
+        if shape is not None:
+            vox = random_volume(rng, shape, "smooth" if shape == (24, 24, 24) else "noise")
+            tree = oracle.build_kdt(vox, "AlwaysCenter")
+        nodes, rd, _ = tree
+        for cam in (None, (30.0, -200.0, 17.0), (4.0, 5.0, -60.0)):
+            pos, forw, up = oracle.main_camera(vox.shape) if cam is None else oracle.main_camera(vox.shape, cam)
+            got = emu_union(emu_lib, nodes, rd, pos, forw, up, W, H, 2.0 if cam is None else 0.4, b, n, max_trips=3)
+            assert got["suspect_differs"] == 0, got
+            n_suspect += got["suspect"]; n_states += got["states"]
+    assert n_suspect >= 10 and n_states > 100 * n_suspect, (n_suspect, n_states)
