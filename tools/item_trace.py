@@ -2,17 +2,20 @@
 """GPU box, measuring build (tools/tune_build.sh items -DVR_MEASURE -DVR_SWEEP_MAX_BLOCKS=256): the rounds of ONE
 (ray, block) item of the union kernel's Skull sweep, one line per round: round, us since the launch began, lanes of its wave
 holding a front, lanes descending, whether the traced lane is popping.
-usage: VR_LIB_PATH=.../libvr_items.so VR_SWEEP_ITEMS=3 python tools/item_trace.py ray block blocks_per_ray out.txt"""
+usage: VR_LIB_PATH=.../libvr_items.so VR_SWEEP_ITEMS=3 python tools/item_trace.py ray block blocks_per_ray out.txt [skull|c60|standin256]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import volumerenderer_amd as vr
-from volumerenderer_amd import capi
+from volumerenderer_amd import capi, datasets
 ray, blk, nb, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 os.environ["VR_MEASURE_TRACE"] = "%d,%d,%d" % (ray, blk, nb)
 os.environ["VR_MEASURE_TRACE_OUT"] = out
-data = vr.Data.loadUCD(os.path.join(ROOT, "tests", "data", "Skull.vol.gz"))
+volume = sys.argv[5] if len(sys.argv) > 5 else "skull"
+data = {"skull": lambda: vr.Data.loadUCD(os.path.join(ROOT, "tests", "data", "Skull.vol.gz")),
+        "c60": lambda: vr.Data.loadUCD(os.path.join(ROOT, "tests", "data", "C60.vol")),
+        "standin256": lambda: vr.Data(datasets.bonsai_standin())}[volume]()
 pos, forw, up = vr.main_camera(data.resulution)
 L = capi.lib()
 r = vr.Renderer(0); r.upload_volume(data); r.build_kdt("AlwaysCenter")
