@@ -42,9 +42,12 @@ constexpr uint32_t kTileW = 8, kTileH = 8;     /* pixels per wave               
 constexpr uint32_t kBlockW = 16, kBlockH = 16; /* pixels per 256-thread block (2x2 waves) */
 constexpr uint32_t kTopNodes = 4095;           /* heap levels 0..11, 16 KiB of LDS        */
 #ifndef VR_REFILL_MIN
-#define VR_REFILL_MIN 16
+#define VR_REFILL_MIN 64
 #endif
-constexpr uint32_t kRefillMin = VR_REFILL_MIN; /* refill a wave once this many lanes idle */
+/* a wave takes new rays once this many of its lanes are idle.  64 = the whole wave: it then always holds ONE tile of 64 neighbouring
+ * rays, whose walks read the same nodes and end at about the same time (Skull 4096^2 iso 80: 0.945 ms with 16, 0.834 with 64; C60 1024^2
+ * iso 100: 0.147 / 0.140; Skull 1024^2 iso 80, 1.16 rays per lane: the same) */
+constexpr uint32_t kRefillMin = VR_REFILL_MIN;
 #ifndef VR_DESCEND_TRIPS
 #define VR_DESCEND_TRIPS 6
 #endif
@@ -1199,8 +1202,11 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
                                * C60 0.733 / 0.724 with 9 / 11, 256^3 stand-in 2.51 / 2.49) */
 #endif
 #ifndef VR_UNION_REFILL_MIN
-#define VR_UNION_REFILL_MIN 24 /* idle lanes from which a wave takes new items (Skull / C60 / stand-in sweep, ms: 16: 1.048 / 0.788 / 2.71,
-                                * 24: 1.020 / 0.766 / 2.65, 32: 1.015 / 0.777 / 2.69; 8: 1.17 on Skull) */
+#define VR_UNION_REFILL_MIN 64 /* idle lanes from which a wave takes new items.  64 = only when the whole wave is idle: a wave then always holds
+                                * the 64 neighbouring rays of ONE tile for ONE block of iso values, fronts that read the same nodes and end at about
+                                * the same time.  Skull / C60 / 256^3 stand-in sweep, kernel ms: 24: 0.905 / 0.717 / 2.48, 32: 0.884 / 0.711 / 2.53,
+                                * 48: 0.867 / 0.701 / 2.64, 56: 0.875 / 0.701 / 2.73 (idle lanes without the coherence), 64: 0.867 / 0.697 / 2.34;
+                                * 32 iso values of the 1024^3 gyroid at 4096^2: 10.19 / 9.80 with 24 / 64 */
 #endif
 constexpr uint32_t kUnionDescendTrips = VR_UNION_DESCEND_TRIPS, kUnionPopTrips = VR_UNION_POP_TRIPS;
 constexpr uint32_t kUnionRefillMin = VR_UNION_REFILL_MIN;
