@@ -66,6 +66,10 @@ for f in late:
     ray, blk = divmod(int(f), n_blocks)
     say("  ends last: ray %6d block %2d  length %4d  began %6.1f us  took %6.1f us (%.2f us per unit of length)" % (
         ray, blk, rounds[f], begin[f] / 100.0, ticks[f] / 100.0, ticks[f] / 100.0 / max(1, rounds[f])))
+for f in np.argsort(ticks)[::-1][:4]:
+    ray, blk = divmod(int(f), n_blocks)
+    say("  takes longest: ray %6d block %2d  length %4d  began %6.1f us  took %6.1f us (%.2f us per unit of length)" % (
+        ray, blk, rounds[f], begin[f] / 100.0, ticks[f] / 100.0, ticks[f] / 100.0 / max(1, rounds[f])))
 # what could another order of the tiles gain?  List scheduling of (tile, block) units on 4096 wave slots; a unit lasts as long as
 # its longest item did in this launch.  Orders: as the launch took them, by the tile's measured time, by its longest item in rounds.
 import heapq

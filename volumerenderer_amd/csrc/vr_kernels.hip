@@ -1477,6 +1477,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     VR_MEASURE_LANE(measure);
     VR_MEASURE_DIMS(n_active, n_blocks, block_isos, iso_begin);
     bool alive = false, exhausted = false, popping = false, suspect = false;
+    const uint32_t n_tiles_all = (n_active + 63u) >> 6;
 
     for (;;) {
         /* ---- refill idle lanes from the ray queue ---- */
@@ -1498,6 +1499,15 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     start = true; s_ray = ray; s_iso = iso_begin + b0; s_n = b1 - b0;
                     n_walks++;
                 }
+            }
+            if (ordered) {
+                /* The launch lasts as long as its longest items, and those are the first of the order: the waves that hold a tile of
+                 * its first 1/32 issue ahead of the others on their SIMD, those of its first 1/8 ahead of the rest (a wave holds one
+                 * tile at a time).  Skull sweep 0.867 -> 0.857 ms, 256^3 stand-in 2.35 -> 2.29, C60 0.700 -> 0.694. */
+                const uint32_t at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(got ? mine / (64u * n_blocks) : 0xffffffu));
+                if (at0 < (n_tiles_all >> 5)) __builtin_amdgcn_s_setprio(3);
+                else if (at0 < (n_tiles_all >> 3)) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
             }
             exhausted = chunk.exhausted();
             if (exhausted && !tick_empty) tick_empty = __builtin_amdgcn_s_memrealtime();

@@ -128,7 +128,8 @@ VR_HD void vr_union_need_bits(Done &done, ULane &U)
     U.holes = true;
 }
 
-/* after marking: pulls alive_lo / alive_hi in to the nearest iso values that are not done */
+/* after marking: pulls alive_lo / alive_hi in to the nearest iso values that are not done; when no done iso value is left
+ * between them -- the hole has reached an end of the range -- the two bounds say it all again and the bits are dropped */
 template <class Done, class ULane>
 VR_HD void vr_union_shrink(const Done &done, ULane &U)
 {
@@ -143,6 +144,16 @@ VR_HD void vr_union_shrink(const Done &done, ULane &U)
         if (w == 0u) { U.alive_lo = 1u; U.alive_hi = 0u; break; }
         U.alive_hi = (w << 5) - 1u;
     }
+#ifndef VR_UNION_KEEP_HOLES
+    if (U.holes && U.alive_lo <= U.alive_hi) {
+        uint32_t any = 0u;
+        for (uint32_t w = U.alive_lo >> 5; w <= (U.alive_hi >> 5); w++) {
+            const uint32_t a = w == (U.alive_lo >> 5) ? (U.alive_lo & 31u) : 0u, b = w == (U.alive_hi >> 5) ? (U.alive_hi & 31u) : 31u;
+            any |= done.word(w) & (0xffffffffu >> (31u - b)) & (0xffffffffu << a);
+        }
+        if (any == 0u) U.holes = false;
+    }
+#endif
 }
 
 template <class Stack, class Done>
