@@ -95,6 +95,8 @@ def test_union_kernel_repeated_calls_start_their_tiles_longest_first_with_the_sa
             assert (got[1] == ref[1]).all(), (i, np.argwhere(got[1] != ref[1])[:8])
             assert bool(torch.equal(got[0], ref[0])), i
             capi.check(L.vr_sweep_info_read(rnd.handle, C.byref(si)), "vr_sweep_info_read")
+            # one walk per item, also once the first tiles of the order are cut into more blocks of iso values than the rest
+            assert si.walks == si.items and si.rendered_again == 0, (W, i, si.walks, si.items)
             # a call the context remembers is ordered unless the list is long (the context may remember this one from an earlier test)
             if i > 0 or W >= 4096:
                 assert si.tiles_longest_first == (1 if W < 4096 else 0), (W, i, si.tiles_longest_first)

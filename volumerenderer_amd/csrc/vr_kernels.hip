@@ -1201,6 +1201,14 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
 #define VR_UNION_POP_TRIPS 11 /* levels up per round (Skull sweep, with one exit-plane check per pop: 1.000 ms with 9, 0.986 with 11, 0.990 with 13;
                                * C60 0.733 / 0.724 with 9 / 11, 256^3 stand-in 2.51 / 2.49) */
 #endif
+#ifndef VR_UNION_FINE_SHIFT
+#define VR_UNION_FINE_SHIFT 4 /* the first 1/16 of the tiles of a settled order ... */
+#endif
+#ifndef VR_UNION_FINE_MUL
+#define VR_UNION_FINE_MUL 2   /* ... are cut into twice as many blocks of iso values (1: one cut for all).  Skull / C60 / 256^3 stand-in sweep,
+                               * kernel ms: one cut 0.846 / 0.684 / 2.20; first 1/16 x 2: 0.845 / 0.609 / 2.11; 1/8 x 2: 0.839 / 0.617 / 2.11;
+                               * 1/4 x 2: 0.875 / 0.634 / 2.13; 1/16 x 4: 0.874 / 0.630 / 2.21 */
+#endif
 #ifndef VR_UNION_REFILL_MIN
 #define VR_UNION_REFILL_MIN 64 /* idle lanes from which a wave takes new items.  64 = only when the whole wave is idle: a wave then always holds
                                 * the 64 neighbouring rays of ONE tile for ONE block of iso values, fronts that read the same nodes and end at about
@@ -1211,6 +1219,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_sweep(
 constexpr uint32_t kUnionDescendTrips = VR_UNION_DESCEND_TRIPS, kUnionPopTrips = VR_UNION_POP_TRIPS;
 constexpr uint32_t kUnionRefillMin = VR_UNION_REFILL_MIN;
 constexpr uint32_t kParkMoveShift = 35u; /* see UnionSink::park */
+constexpr uint32_t kUnionFineShift = VR_UNION_FINE_SHIFT, kUnionFineMul = VR_UNION_FINE_MUL;
 constexpr uint32_t kUnionMaxStates = 1u << 20; /* MOVEs of one front: the safety valve (VR_MAX_CHECKED in the other kernels) */
 
 struct VrUnionRecord { uint32_t ray, run, t_bits, cell, esc, pad[3]; }; /* run = r0 | r1 << 8 | in_root << 16 */
@@ -1453,7 +1462,7 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     nb = nb < 1u ? 1u : (nb > VR_SWEEP_MAX_BLOCKS ? VR_SWEEP_MAX_BLOCKS : nb);
     nb = nb > iso_count ? iso_count : nb;
     const uint32_t block_isos = (iso_count + nb - 1u) / nb, n_blocks = (iso_count + block_isos - 1u) / block_isos;
-    const uint32_t n_items = ((n_active + 63u) & ~63u) * n_blocks;
+    uint32_t n_items = ((n_active + 63u) & ~63u) * n_blocks;
     unsigned long long *info = (unsigned long long *)(n_active_ptr + 16);
     const unsigned long long tick_begin = __builtin_amdgcn_s_memrealtime();
     unsigned long long tick_empty = 0;
@@ -1478,6 +1487,22 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     VR_MEASURE_DIMS(n_active, n_blocks, block_isos, iso_begin);
     bool alive = false, exhausted = false, popping = false, suspect = false;
     const uint32_t n_tiles_all = (n_active + 63u) >> 6;
+    /* Two cuts in one launch: the first tiles of an order that is in place and no longer measured -- the longest of the launch --
+     * are cut into kUnionFineMul times as many blocks of iso values as the rest.  A launch lasts as long as its longest items, and
+     * where those are long because of how many iso values they carry, the finer cut shortens them, while cutting every tile
+     * finer costs more in all than it gains (C60 sweep 0.684 -> 0.609 ms, 256^3 stand-in 2.20 -> 2.11; Skull, whose longest item
+     * is one ray's walk for a few iso values: 0.846 -> 0.844).  Items [0, fine_items) are the fine ones.  (The measuring build
+     * keeps one cut: its item table has one shape.) */
+#ifdef VR_MEASURE
+    const uint32_t fine_tiles = 0u;
+#else
+    const uint32_t fine_tiles = ordered && !length_out ? n_tiles_all >> kUnionFineShift : 0u;
+#endif
+    uint32_t nbf = n_blocks * kUnionFineMul;
+    nbf = nbf > iso_count ? iso_count : nbf;
+    const uint32_t fine_isos = (iso_count + nbf - 1u) / nbf, n_fine_blocks = (iso_count + fine_isos - 1u) / fine_isos;
+    const uint32_t fine_items = fine_tiles * 64u * n_fine_blocks;
+    n_items = fine_items + (((n_active + 63u) >> 6) - fine_tiles) * 64u * n_blocks;
 
     for (;;) {
         /* ---- refill idle lanes from the ray queue ---- */
@@ -1491,11 +1516,14 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             uint32_t mine;
             const bool got = chunk.take(n_idle, (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), head, n_items, n_idle, lane, mine);
             if (!alive && got) {
-                const uint32_t at = mine / (64u * n_blocks), in = mine - at * 64u * n_blocks;
+                const bool fine = mine < fine_items;
+                const uint32_t per_tile = 64u * (fine ? n_fine_blocks : n_blocks), rel = fine ? mine : mine - fine_items;
+                const uint32_t at = (fine ? 0u : fine_tiles) + rel / per_tile, in = rel % per_tile;
+                const uint32_t u_isos = fine ? fine_isos : block_isos;
                 const uint32_t grp = ordered ? tile_order[at] : at; /* longest tiles of the previous launch first */
                 const uint32_t blk = in >> 6, ray = grp * 64u + (in & 63u);
                 if (ray < n_active) { /* the last group of 64 may be short */
-                    const uint32_t b0 = blk * block_isos, b1 = b0 + block_isos < iso_count ? b0 + block_isos : iso_count;
+                    const uint32_t b0 = blk * u_isos, b1 = b0 + u_isos < iso_count ? b0 + u_isos : iso_count;
                     start = true; s_ray = ray; s_iso = iso_begin + b0; s_n = b1 - b0;
                     n_walks++;
                 }
@@ -1504,7 +1532,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                 /* The launch lasts as long as its longest items, and those are the first of the order: the waves that hold a tile of
                  * its first 1/32 issue ahead of the others on their SIMD, those of its first 1/8 ahead of the rest (a wave holds one
                  * tile at a time).  Skull sweep 0.867 -> 0.857 ms, 256^3 stand-in 2.35 -> 2.29, C60 0.700 -> 0.694. */
-                const uint32_t at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(got ? mine / (64u * n_blocks) : 0xffffffu));
+                const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+                const uint32_t at0 = !got ? 0xffffffu : m0 < fine_items ? m0 / (64u * n_fine_blocks) : fine_tiles + (m0 - fine_items) / (64u * n_blocks);
                 if (at0 < (n_tiles_all >> 5)) __builtin_amdgcn_s_setprio(3);
                 else if (at0 < (n_tiles_all >> 3)) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
@@ -1620,8 +1649,17 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     if (threadIdx.x == 0) {
         atomicAdd(&info[0], (unsigned long long)s_cnt[kSweepCounters * n_k]);
         if (blockIdx.x == 0 && tile_cost) *(tile_cost - kLptHeaderWords) = (n_active + 63u) >> 6;
-        if (blockIdx.x == 0) { info[1] = n_active * n_blocks; info[5] = launch_seq; }
+        if (blockIdx.x == 0) { /* items of the launch: a ray of a fine tile has n_fine_blocks of them */
+            atomicAdd(&info[1], (unsigned long long)n_active * n_blocks + (unsigned long long)fine_tiles * 64u * (n_fine_blocks - n_blocks));
+            info[5] = launch_seq; /* (the pre-pass has left info[1] at zero; the correction below is an atomic as well) */
+        }
         atomicMax(&info[4], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+    if (blockIdx.x == 0 && (n_active & 63u) != 0u && n_fine_blocks != n_blocks) {
+        /* the last tile of the list is short: if it is one of the fine ones, the rays it lacks have no items */
+        for (uint32_t i = threadIdx.x; i < fine_tiles; i += kTraceThreads)
+            if (tile_order[i] == n_tiles_all - 1u)
+                atomicAdd(&info[1], 0ull - (unsigned long long)(64u - (n_active & 63u)) * (n_fine_blocks - n_blocks));
     }
     if (threadIdx.x < kSweepCounters) {
         uint32_t *c = s_cnt + threadIdx.x * n_k;
