@@ -1487,6 +1487,8 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     VR_MEASURE_DIMS(n_active, n_blocks, block_isos, iso_begin);
     bool alive = false, exhausted = false, popping = false, suspect = false;
     const uint32_t n_tiles_all = (n_active + 63u) >> 6;
+    uint32_t wave_age = 0u; /* rounds since the wave took its tile */
+    (void)wave_age;
     /* Two cuts in one launch: the first tiles of an order that is in place and no longer measured -- the longest of the launch --
      * are cut into kUnionFineMul times as many blocks of iso values as the rest.  A launch lasts as long as its longest items, and
      * where those are long because of how many iso values they carry, the finer cut shortens them, while cutting every tile
@@ -1528,16 +1530,10 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
                     n_walks++;
                 }
             }
-            if (ordered) {
-                /* The launch lasts as long as its longest items, and those are the first of the order: the waves that hold a tile of
-                 * its first 1/32 issue ahead of the others on their SIMD, those of its first 1/8 ahead of the rest (a wave holds one
-                 * tile at a time).  Skull sweep 0.867 -> 0.857 ms, 256^3 stand-in 2.35 -> 2.29, C60 0.700 -> 0.694. */
-                const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
-                const uint32_t at0 = !got ? 0xffffffu : m0 < fine_items ? m0 / (64u * n_fine_blocks) : fine_tiles + (m0 - fine_items) / (64u * n_blocks);
-                if (at0 < (n_tiles_all >> 5)) __builtin_amdgcn_s_setprio(3);
-                else if (at0 < (n_tiles_all >> 3)) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-            }
+#ifndef VR_UNION_NO_PRIO
+            wave_age = 0u;
+            __builtin_amdgcn_s_setprio(0);
+#endif
             exhausted = chunk.exhausted();
             if (exhausted && !tick_empty) tick_empty = __builtin_amdgcn_s_memrealtime();
         }
@@ -1554,6 +1550,16 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
             continue; /* fewer idle lanes than a refill takes cannot happen with nobody alive, but stay safe */
         }
         VR_MEASURE_DO(measure.round(alive, popping, tick_begin));
+        /* The launch lasts as long as its longest items: a wave that has been at its tile for 16 rounds issues ahead of the younger
+         * ones on its SIMD, from 48 rounds on ahead of everybody (a wave holds one tile at a time; the priority goes back to 0 with
+         * the next tile).  Skull / C60 / 256^3 stand-in sweep, kernel ms: no priorities (-DVR_UNION_NO_PRIO) 0.841 / 0.616 / 2.115;
+         * these 0.848 / 0.622 / 1.954; by the tile's place in the order instead (first 1/32: 3, first 1/8: 1) 0.845 / 0.612 / 2.105;
+         * both: 0.865 / 0.655 / 2.00. */
+#ifndef VR_UNION_NO_PRIO
+        wave_age++;
+        if (wave_age == 16u) __builtin_amdgcn_s_setprio(2);
+        else if (wave_age == 48u) __builtin_amdgcn_s_setprio(3);
+#endif
         if (alive) {
             /* the item's length for the next launch's order, in half rounds: a round of a wave in which some lane has a hole in its
              * open iso values goes through the done-bit code and takes about one and a half times as long (Skull sweep: tiles ordered
