@@ -243,6 +243,48 @@ def test_device_entry_point_rows_and_isos(oracle, c60_vox, c60_tree, c60_rendere
     assert checked == sum(s["nodes_checked"] for s in full["stats"])
 
 
+def test_calls_that_share_a_ray_list_match_the_oracle(oracle, skull_vox, skull_tree, skull_renderer):
+    """The ray list of a call depends on the camera, the image size and the rows, not on the iso values: a context keeps the
+    list of its last call and the next call with the same view does not make it again.  An iso slider at a fixed camera,
+    with sweeps (another kind of list), other rows, another image size and another camera in between: every frame and
+    every counter equals the oracle's, whatever came before."""
+    import torch
+    nodes, rd, _ = skull_tree
+    pos, forw, up = oracle.main_camera(skull_vox.shape)
+    pos2 = (pos[0] + 7.0, pos[1] - 3.0, pos[2] + 1.0)
+    L = capi.lib()
+
+    def call(p, W, H, b, n, r0, r1, with_stats=True):
+        v = vr.raytrace._view(p, forw, up, W, H, 2.0)
+        d_rgb = torch.full((n, r1 - r0, W, 3), 9, dtype=torch.uint8, device="cuda")
+        d_stats = torch.zeros((n, 7), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        capi.check(L.vr_render_device(skull_renderer.handle, C.byref(v), b, n, r0, r1, d_rgb.data_ptr(),
+                                      d_stats.data_ptr() if with_stats else None, None, None), "vr_render_device")
+        capi.check(L.vr_sync(skull_renderer.handle), "vr_sync")
+        rgb, st = d_rgb.cpu().numpy(), d_stats.cpu().numpy()
+        for j in (0, n - 1) if n > 1 else (0,):
+            ref = oracle.render(nodes, rd, p, forw, up, W, H, 2.0, b + j)
+            assert (rgb[j] == ref["rgb"][r0:r1]).all(), ("pixels", W, H, b + j, r0, r1)
+            if with_stats and r0 == 0 and r1 == H:
+                o = ref["stats"]
+                assert st[j].tolist() == [o.nodes_checked, o.hit_count, o.miss_count, o.oob_count, o.escape_help_events, o.moves, 0], (W, H, b + j)
+
+    W, H = 160, 120
+    for b in (80, 120, 40):              # the slider: one list, three calls
+        call(pos, W, H, b, 1, 0, H)
+    call(pos, W, H, 30, 12, 0, H)        # a sweep: rays from the tile centres outwards, a list of its own
+    call(pos, W, H, 60, 16, 0, H)        # ... kept for the next sweep
+    call(pos, W, H, 90, 1, 0, H)         # back to a frame
+    call(pos, W, H, 90, 3, 10, 97)       # other rows
+    call(pos, W, H, 100, 1, 10, 97, with_stats=False)
+    call(pos, 96, 64, 100, 1, 0, 64)     # another image size
+    call(pos2, 96, 64, 100, 2, 0, 64)    # another camera, same size
+    call(pos, 96, 64, 100, 2, 0, 64)
+    call(pos, 512, 512, 70, 1, 0, 512)   # a larger view: the scratch grows and the list goes with the old buffer
+    call(pos, 512, 512, 75, 1, 0, 512)
+
+
 def test_error_paths_on_device(c60_tree):
     nodes, rd, _ = c60_tree
     L = capi.lib()

@@ -111,6 +111,17 @@ struct vr_ctx {
     } lpts[kRemember];
     uint64_t use_clock = 0;
     uint64_t tree_id = 0;                 /* changes with every upload / build */
+    /* The ray list that the last pipeline launch left in d_work: it depends on the view (camera, image size, the volume's box),
+     * the rows and whether the kernel wants rays from pixel centres outwards -- not on the iso values or the tree -- so the next
+     * call with the same ones on the same stream does not make it again (an iso slider at a fixed camera, a repeated sweep:
+     * two launches fewer per call). */
+    struct ListKey {
+        bool valid = false;
+        VrViewK view;
+        uint32_t row_begin = 0, row_end = 0;
+        bool centered = false;
+        hipStream_t stream = nullptr;
+    } list;
     unsigned long long *h_info = nullptr; /* page-locked: walks, items, 3 ticks, sequence number */
     /* options */
     int variant = VR_KERNEL_DEFAULT;
@@ -614,7 +625,10 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         if (!per_pixel) {
             /* growing the scratch is the only allocation on this path; it happens when a larger view comes */
             const size_t need = vr_pipeline_workspace_bytes(view->width, row_end - row_begin, iso_count);
-            if (need > c->work_cap) VR_HIP(hipStreamSynchronize(s));
+            if (need > c->work_cap) {
+                VR_HIP(hipStreamSynchronize(s));
+                c->list.valid = false; /* the list goes with the old buffer */
+            }
             rc = ensure(&c->d_work, &c->work_cap, need);
             if (rc != VR_OK) return rc;
         }
@@ -696,13 +710,26 @@ static int render_device(vr_ctx *c, const vr_view *view, uint32_t iso_begin, uin
         u.have = false; /* until the launch is known to be enqueued */
     }
     void *lpt_mem = lpt ? lpt->mem : nullptr;
+    /* the ray list of the context's last pipeline launch, when it is this call's (see vr_ctx::ListKey) */
+    static const bool keep_list_off = std::getenv("VR_KEEP_LIST") && std::atoi(std::getenv("VR_KEEP_LIST")) == 0; /* for A/B runs */
+    const bool own_list = !fixed_scratch && !per_pixel; /* per-pixel kernels have no list and leave the one in d_work alone */
+    const bool centered = sweep_kernel || union_kernel;
+    bool list_state = own_list && !keep_list_off && c->list.valid && c->list.stream == s && same_view(c->list.view, k) &&
+                      c->list.row_begin == row_begin && c->list.row_end == row_end && c->list.centered == centered;
+    bool *const list_arg = own_list ? &list_state : nullptr;
+    if (own_list) c->list.valid = false; /* until the launch is known to be enqueued */
     if (c->wide)
         VR_HIP(vr_launch_render_wide(variant, s, k, c->d_nodes, iso_begin, iso_count, row_begin, row_end, (uint8_t *)d_rgb24,
-                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq, c->ranges_nested, lpt_mode, lpt_mem));
+                                     (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq, c->ranges_nested, lpt_mode, lpt_mem,
+                                     list_arg));
     else
         VR_HIP(vr_launch_render(variant, s, k, c->d_nodes, c->d_prepared, c->max_depth, iso_begin, iso_count, row_begin,
                                 row_end, (uint8_t *)d_rgb24, (vr_render_stats *)d_stats, taps, work, c->n_cus, ev0, ev1, ipl, seq,
-                                c->ranges_nested, lpt_mode, lpt_mem));
+                                c->ranges_nested, lpt_mode, lpt_mem, list_arg));
+    if (own_list && list_state) {
+        c->list.valid = true; c->list.view = k; c->list.row_begin = row_begin; c->list.row_end = row_end;
+        c->list.centered = centered; c->list.stream = s;
+    }
     if (lpt) lpt->have = true;
     if (timing) c->ev_used += 2;
     if ((sweep_kernel || union_kernel) && !fixed_scratch) {

@@ -74,12 +74,16 @@ size_t vr_pipeline_info_offset(uint32_t width, uint32_t n_rows);
 
 /* Enqueues the kernels that render rows [row_begin,row_end) of iso_count frames.  d_nodes_raw is the
  * reference's SlimNode array, d_nodes_prepared the flattened form of vr_host_prepare_kdt.  The
- * dominant traversal kernel is bracketed by ev_begin / ev_end when they are not null. */
+ * dominant traversal kernel is bracketed by ev_begin / ev_end when they are not null.
+ * list_state (may be null): in, true = the workspace still holds the ray list of this very view, rows and kind of
+ * kernel (the caller's last pipeline launch on it, same stream), so the pre-pass does not make it again; out,
+ * true = the launch went through the pipeline and the workspace holds its list now. */
 hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view, const uint32_t *d_nodes_raw,
                             const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
                             const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end,
-                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested, int lpt_mode, void *lpt_mem);
+                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested, int lpt_mode, void *lpt_mem,
+                            bool *list_state = nullptr);
 
 /* Once per device, with that device current (vr_ctx_create calls it; safe from several threads): raises the
  * dynamic-LDS ceiling of the persistent kernels, which is a property of the function on the device, and looks
@@ -115,7 +119,7 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
                                  uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
                                  hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq,
-                                 bool ranges_nested, int lpt_mode, void *lpt_mem);
+                                 bool ranges_nested, int lpt_mode, void *lpt_mem, bool *list_state = nullptr);
 
 
 /* One ray with the literal loop, every iteration recorded (vr_refine.hip): d_steps holds cap records, d_report one. */

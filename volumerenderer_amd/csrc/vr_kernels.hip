@@ -450,7 +450,7 @@ __global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, 
                                                   uint32_t *__restrict__ heads, uint32_t iso_count,
                                                   vr_render_stats *__restrict__ stats, uint64_t frame_pixels, uint32_t n_tiles,
                                                   uint32_t *__restrict__ tile_cost, uint32_t *__restrict__ tile_order,
-                                                  uint32_t order_max_tiles, uint32_t *__restrict__ chord_header)
+                                                  uint32_t order_max_tiles, uint32_t *__restrict__ chord_header, uint32_t list_kept)
 {
     if (blockIdx.x == 1u) { /* launched only when the union kernel's tile order is wanted: it rides along on a block of its own */
         tile_order_step(n_tiles, tile_cost, tile_order, order_max_tiles, 1u); /* the same list as this call's: same call */
@@ -459,7 +459,9 @@ __global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, 
     __shared__ uint32_t s_wave[16];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t per = ((n + 15u) / 16u + 63u) & ~63u; /* values per wave, a multiple of 64 */
-    const uint32_t b = wave * per, e = b + per < n ? b + per : n;
+    /* list_kept: the ray list of the last call on this workspace is this call's (same view, same rows): the offsets and the
+     * total are in place, only the set-up work below is done */
+    const uint32_t b = wave * per, e = list_kept ? b : (b + per < n ? b + per : n);
     uint32_t sum = 0;
     for (uint32_t i = b + lane; i < e; i += 64u) sum += count[i];
     sum = wave_sum(sum);
@@ -472,6 +474,7 @@ __global__ __launch_bounds__(1024) void vr_k_scan(uint32_t *__restrict__ count, 
         run += w < wave ? c : 0u;
         total += c;
     }
+    if (list_kept) total = *n_active_out;
     for (uint32_t i0 = b; i0 < e; i0 += 64u) {
         const uint32_t i = i0 + lane;
         const uint32_t c = i < e ? count[i] : 0u;
@@ -2144,7 +2147,7 @@ struct Prepass {
 hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_count, uint32_t row_begin, uint32_t n_rows,
                           uint32_t center_out, uint8_t *d_rgb, vr_render_stats *d_stats, const VrTapsK &taps,
                           uint32_t oob_word, void *workspace, Prepass &pp, uint32_t *tile_cost = nullptr, uint32_t *tile_order = nullptr,
-                          uint32_t grid_lanes = 0, uint32_t *chord_order = nullptr)
+                          uint32_t grid_lanes = 0, uint32_t *chord_order = nullptr, bool list_kept = false)
 {
     const size_t n_pix = (size_t)view.width * n_rows;
     const uint32_t n_blocks = padded_tiles(view.width, n_rows) / (kSuper * kSuper);
@@ -2162,14 +2165,18 @@ hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_
     hipError_t e;
     const bool any_tap = taps.cell_flag || taps.t || taps.checked || taps.node;
     /* the frames start black: a memset for sweeps, the count kernel's own threads for the few frames of a short call */
-    const uint32_t clear_isos = iso_count < kCountClearsBelow && n_pix * iso_count <= kCountClearsPixels ? iso_count : 0u;
+    /* (a kept list: no count kernel, so a memset in every case; the compact kernel runs only for the chords of a first call -- it
+     * writes the same list again) */
+    const uint32_t clear_isos = !list_kept && iso_count < kCountClearsBelow && n_pix * iso_count <= kCountClearsPixels ? iso_count : 0u;
     if (!clear_isos && (e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(vr_k_count, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt, d_rgb, clear_isos);
+    if (!list_kept)
+        hipLaunchKernelGGL(vr_k_count, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt, d_rgb, clear_isos);
     hipLaunchKernelGGL(vr_k_scan, dim3(tile_order ? 2 : 1), dim3(1024), 0, stream, block_cnt, n_blocks, pp.n_active, pp.heads, iso_count, d_stats,
                        (uint64_t)n_pix, (uint32_t)((n_pix + 63u) / 64u), tile_cost, tile_order, lpt_max_tiles(grid_lanes),
-                       chord_order ? tile_cost - kLptHeaderWords : (uint32_t *)nullptr);
-    hipLaunchKernelGGL(vr_k_compact, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt,
-                       pp.ray_dt, pp.ray_pix, chord_order ? tile_cost : (uint32_t *)nullptr, lpt_max_tiles(grid_lanes), pp.n_active);
+                       chord_order ? tile_cost - kLptHeaderWords : (uint32_t *)nullptr, list_kept ? 1u : 0u);
+    if (!list_kept || chord_order)
+        hipLaunchKernelGGL(vr_k_compact, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt,
+                           pp.ray_dt, pp.ray_pix, chord_order ? tile_cost : (uint32_t *)nullptr, lpt_max_tiles(grid_lanes), pp.n_active);
     if (chord_order) /* a first call: the order from the chords the kernel above has left */
         hipLaunchKernelGGL(vr_k_tile_order, dim3(1), dim3(1024), 0, stream, (uint32_t)((n_pix + 63u) / 64u), tile_cost, chord_order,
                            lpt_max_tiles(grid_lanes));
@@ -2326,8 +2333,11 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
                             const uint32_t *d_nodes_prepared, uint32_t max_depth, uint32_t iso_begin, uint32_t iso_count,
                             uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb, vr_render_stats *d_stats,
                             const VrTapsK &taps, void *workspace, int n_cus, hipEvent_t ev_begin, hipEvent_t ev_end,
-                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested, int lpt_mode, void *lpt_mem)
+                            uint32_t sweep_items_per_lane, uint32_t launch_seq, bool ranges_nested, int lpt_mode, void *lpt_mem,
+                            bool *list_state)
 {
+    const bool list_kept = list_state && *list_state; /* in: the workspace holds this call's ray list; out: it does now */
+    if (list_state) *list_state = false;
     const uint32_t n_rows = row_end - row_begin;
     const uint32_t stack_levels = max_depth > 0 ? max_depth : 1u;
     const bool want_union = variant == VR_KERNEL_UNION;
@@ -2381,8 +2391,10 @@ hipError_t vr_launch_render(int variant, hipStream_t stream, const VrViewK &view
     if (use_union && (e = lpt_prepare(stream, lpt_mode, lpt_mem, view, n_rows, &tile_order, &sort_into, &chord_into, &tile_cost, &keep_lengths)) != hipSuccess)
         return e;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
-                            VR_FLAG_OOB << 24, workspace, pp, tile_cost, sort_into, (uint32_t)n_cus * kTraceBlocksPerCu * kTraceThreads, chord_into)) != hipSuccess)
+                            VR_FLAG_OOB << 24, workspace, pp, tile_cost, sort_into, (uint32_t)n_cus * kTraceBlocksPerCu * kTraceThreads, chord_into,
+                            list_kept)) != hipSuccess)
         return e;
+    if (list_state) *list_state = true;
     float4 *ray_dt = pp.ray_dt;
     uint32_t *ray_pix = pp.ray_pix, *n_active = pp.n_active, *heads = pp.heads;
 
@@ -2459,8 +2471,10 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
                                  uint32_t iso_begin, uint32_t iso_count, uint32_t row_begin, uint32_t row_end, uint8_t *d_rgb,
                                  vr_render_stats *d_stats, const VrTapsK &taps, void *workspace, int n_cus,
                                  hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t sweep_items_per_lane, uint32_t launch_seq,
-                                 bool ranges_nested, int lpt_mode, void *lpt_mem)
+                                 bool ranges_nested, int lpt_mode, void *lpt_mem, bool *list_state)
 {
+    const bool list_kept = list_state && *list_state; /* as in vr_launch_render */
+    if (list_state) *list_state = false;
     const uint32_t n_rows = row_end - row_begin;
     hipError_t e = hipSuccess;
     if (variant == VR_KERNEL_RESTART_GLOBAL || variant == VR_KERNEL_RESTART_LDS || variant == VR_KERNEL_RESUME) {
@@ -2483,8 +2497,9 @@ hipError_t vr_launch_render_wide(int variant, hipStream_t stream, const VrViewK 
         return e;
     if ((e = launch_prepass(stream, view, iso_count, row_begin, n_rows, sweep ? 1u : 0u, d_rgb, d_stats, taps,
                             VR_FLAG_OOB << VR_WIDE_FLAG_SHIFT, workspace, pp, tile_cost, sort_into,
-                            (uint32_t)n_cus * kTraceBlocksPerCu * kTraceThreads, chord_into)) != hipSuccess)
+                            (uint32_t)n_cus * kTraceBlocksPerCu * kTraceThreads, chord_into, list_kept)) != hipSuccess)
         return e;
+    if (list_state) *list_state = true;
     /* one traversal per ray for the whole iso range, under the same conditions as on narrow trees (vr_launch_render) */
     if (use_union) {
         const uint32_t n_top = 0u, stack_rows = VR_WIDE_MAX_DEPTH;
