@@ -2138,6 +2138,35 @@ __global__ __launch_bounds__(64) void vr_k_ray_timeline(VrViewK v, const uint32_
 }
 #endif
 
+/* The frames of a call set to zero with stores that do not stay in the L2 (16 bytes per lane and turn, the odd bytes at either
+ * end one by one).  hipMemsetAsync writes through the L2 like any store and leaves it full of frame lines: the traversal kernel
+ * behind it then finds none of the tree there -- Skull sweep 0.857 ms behind the memset, 0.800 behind this kernel, which also
+ * takes 0.11 ms for the 805 MB instead of 0.14 (step 1.015 -> 0.94 ms; C60 0.797 -> 0.752). */
+typedef uint32_t vr_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void vr_k_clear_frames(uint8_t *__restrict__ rgb, uint64_t bytes)
+{
+    const uint64_t head = (16u - ((uintptr_t)rgb & 15u)) & 15u, lead = head < bytes ? head : bytes;
+    const uint64_t n16 = (bytes - lead) / 16u;
+    const uint64_t tid = (uint64_t)blockIdx.x * 256u + threadIdx.x, n_threads = (uint64_t)gridDim.x * 256u;
+    vr_u32x4 *mid = (vr_u32x4 *)(rgb + lead);
+    const vr_u32x4 z = { 0u, 0u, 0u, 0u };
+    for (uint64_t i = tid; i < n16; i += n_threads) __builtin_nontemporal_store(z, mid + i);
+    if (tid < lead) rgb[tid] = 0u;
+    const uint64_t tail = lead + n16 * 16u;
+    if (tail + tid < bytes) rgb[tail + tid] = 0u; /* fewer than 16 bytes */
+}
+
+static hipError_t clear_frames(hipStream_t stream, uint8_t *d_rgb, uint64_t bytes)
+{
+    static const bool use_memset = getenv("VR_CLEAR_KERNEL") && atoi(getenv("VR_CLEAR_KERNEL")) == 0; /* for A/B runs */
+    if (use_memset || bytes < 4096u) return hipMemsetAsync(d_rgb, 0, bytes, stream);
+    /* a block per 16 KiB, at most 32 768 blocks (8 192: 0.965 ms per Skull sweep step, 16 384: 0.949, 32 768 ... 131 072: 0.941) */
+    uint64_t blocks = bytes / 16384u;
+    blocks = blocks < 64u ? 64u : (blocks > 32768u ? 32768u : blocks);
+    hipLaunchKernelGGL(vr_k_clear_frames, dim3((uint32_t)blocks), dim3(256), 0, stream, d_rgb, bytes);
+    return hipGetLastError();
+}
+
 /* workspace layout of the pipeline and its pre-pass (entry test once per call, dense ray list in tile order) */
 struct Prepass {
     float4 *ray_dt;
@@ -2168,7 +2197,7 @@ hipError_t launch_prepass(hipStream_t stream, const VrViewK &view, uint32_t iso_
     /* (a kept list: no count kernel, so a memset in every case; the compact kernel runs only for the chords of a first call -- it
      * writes the same list again) */
     const uint32_t clear_isos = !list_kept && iso_count < kCountClearsBelow && n_pix * iso_count <= kCountClearsPixels ? iso_count : 0u;
-    if (!clear_isos && (e = hipMemsetAsync(d_rgb, 0, n_pix * 3u * iso_count, stream)) != hipSuccess) return e;
+    if (!clear_isos && (e = clear_frames(stream, d_rgb, (uint64_t)n_pix * 3u * iso_count)) != hipSuccess) return e;
     if (!list_kept)
         hipLaunchKernelGGL(vr_k_count, dim3(n_blocks), dim3(kPreThreads), 0, stream, view, row_begin, n_rows, center_out, block_cnt, d_rgb, clear_isos);
     hipLaunchKernelGGL(vr_k_scan, dim3(tile_order ? 2 : 1), dim3(1024), 0, stream, block_cnt, n_blocks, pp.n_active, pp.heads, iso_count, d_stats,
