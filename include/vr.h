@@ -238,7 +238,10 @@ int vr_render_sweep(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint32
  * row_begin) starts at d_rgb24 + ((k*(row_end-row_begin) + r) * width) * 3.  d_stats (device,
  * iso_count records, may be NULL) is zeroed and filled on the stream.  d_taps members are device
  * pointers.  `stream` is a hipStream_t (NULL = the context's own stream).  Returns after
- * enqueueing. */
+ * enqueueing.  A context's scratch serves one call at a time: calls on one context that may overlap in time
+ * (different streams) are serialised by the caller or made on contexts of their own.  The scratch keeps the
+ * call's ray list -- which rays enter the volume: camera, image size and rows decide, not the iso values -- and
+ * the next call with the same view and rows on the same stream uses it instead of making it again. */
 int vr_render_device(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint32_t iso_count,
                      uint32_t row_begin, uint32_t row_end, void *d_rgb24, void *d_stats,
                      const vr_taps *d_taps, void *stream);
