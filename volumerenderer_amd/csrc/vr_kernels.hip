@@ -644,13 +644,25 @@ __device__ __forceinline__ uint32_t trace_chunk(uint32_t n_active, uint32_t n_wa
 }
 struct WaveChunk {
     uint32_t next, end; /* uniform over the wave */
+    uint32_t first;     /* items in front of the queue's own: handed out without it (see seed) */
     bool dry;           /* the shared queue has nothing left */
-    __device__ __forceinline__ WaveChunk() : next(0), end(0), dry(false) {}
+    __device__ __forceinline__ WaveChunk() : next(0), end(0), first(0), dry(false) {}
+    /* The first `per_wave` items of every wave of the grid come without the queue: wave w of n_waves starts with items
+     * [w * per_wave, + per_wave), the queue hands out what lies behind n_waves * per_wave.  (A launch begins with every wave
+     * asking at once: 4 096 atomics on one word, served one after the other -- the last wave of a Skull sweep launch had its
+     * first items 48 us after the first wave's start.) */
+    __device__ __forceinline__ void seed(uint32_t w, uint32_t n_waves, uint32_t per_wave, uint32_t n_total)
+    {
+        const uint64_t all = (uint64_t)n_waves * per_wave, at = (uint64_t)w * per_wave;
+        first = all < n_total ? (uint32_t)all : n_total;
+        next = at < n_total ? (uint32_t)at : n_total;
+        end = at + per_wave < n_total ? (uint32_t)(at + per_wave) : n_total;
+    }
     __device__ __forceinline__ void grab(uint32_t *head, uint32_t n_total, uint32_t want, uint32_t lane)
     {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(head, want);
-        base = __builtin_amdgcn_readfirstlane(base);
+        base = __builtin_amdgcn_readfirstlane(base) + first;
         dry = base >= n_total;
         next = dry ? 0u : base;
         end = dry ? 0u : (base + want < n_total ? base + want : n_total);
@@ -1508,6 +1520,10 @@ __global__ __launch_bounds__(kTraceThreads, kTraceWavesPerSimd) void vr_k_union(
     const uint32_t fine_isos = (iso_count + nbf - 1u) / nbf, n_fine_blocks = (iso_count + fine_isos - 1u) / fine_isos;
     const uint32_t fine_items = fine_tiles * 64u * n_fine_blocks;
     n_items = fine_items + (((n_active + 63u) >> 6) - fine_tiles) * 64u * n_blocks;
+#ifndef VR_UNION_NO_SEED
+    /* wave k of block b is wave k * blocks + b of the grid: the first tiles of the order go to different CUs and SIMDs */
+    chunk.seed((threadIdx.x >> 6) * gridDim.x + blockIdx.x, gridDim.x * (kTraceThreads / 64u), 64u, n_items);
+#endif
 
     for (;;) {
         /* ---- refill idle lanes from the ray queue ---- */
