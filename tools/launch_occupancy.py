@@ -97,4 +97,17 @@ say("  in the order the launch began them: %.0f" % makespan(np.argsort(u_begin.m
 say("  tiles by their longest unit's time, longest first: %.0f" % makespan(np.argsort(-u_ticks.max(axis=1), kind="stable")))
 say("  tiles by their longest item's rounds, longest first: %.0f" % makespan(np.argsort(-u_rounds.max(axis=1), kind="stable")))
 say("  tiles by the sum of their units' times, longest first: %.0f" % makespan(np.argsort(-u_ticks.sum(axis=1), kind="stable")))
+def makespan_units(order):
+    slots = [0] * 4096
+    heapq.heapify(slots)
+    end = 0
+    flat = u_ticks.reshape(-1)
+    for u in order:
+        at = heapq.heappop(slots)
+        fin = at + int(flat[u])
+        end = max(end, fin)
+        heapq.heappush(slots, fin)
+    return end / 100.0
+say("  units by their own time, longest first (an order per (tile, block) instead of per tile): %.0f" % makespan_units(np.argsort(-u_ticks.reshape(-1), kind="stable")))
+say("  units by their own rounds, longest first: %.0f" % makespan_units(np.argsort(-u_rounds.reshape(-1), kind="stable")))
 open(out_path, "w").write("\n".join(lines) + "\n")
