@@ -492,6 +492,18 @@ def main():
         del two
         r2.close()
 
+    if world == 1 and not args.no_extras and args.in_flight == 1 and sweep_kernel and main_plan.rays:
+        # The same step for a caller that wants frames only (d_stats = NULL): the union kernel then runs with everything that only
+        # serves the per-iso counters compiled out.  Not the headline: the reference's renderImage returns nodes_checked
+        # (src/raytrace.zig:21,105), so `value` is measured with the counters.
+        class _NoStats:
+            @staticmethod
+            def data_ptr():
+                return None
+        dt_n, rays_n, kms_n, _ = measure(main_plan, False, [(r, main_plan.d_rgb, _NoStats(), stream)])
+        extras["without_counters"] = {"value": rays_n * args.steps / dt_n / 1e6, "unit": "Mrays/s", "ms_per_step": dt_n / args.steps * 1e3,
+                                      "kernel_ms": kms_n, "note": "the same step with d_stats = NULL: frames only, no per-iso counters"}
+
     if rank == 0:
         vol_name = {"skull": "Skull.vol", "c60": "C60.vol", "standin256": "256^3 stand-in", "gyroid1024": "1024^3 gyroid"}[args.volume]
         workload = "%s_%dx%d_iso%d-%d_sweep" % (args.volume, W, H, I0, I0 + IN - 1)

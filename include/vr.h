@@ -236,7 +236,9 @@ int vr_render_sweep(vr_ctx *ctx, const vr_view *view, uint32_t iso_begin, uint32
 /* Device-resident, asynchronous form used for sharded and timed runs: renders image rows
  * [row_begin,row_end) of iso_count frames into DEVICE memory.  Frame k, row r (relative to
  * row_begin) starts at d_rgb24 + ((k*(row_end-row_begin) + r) * width) * 3.  d_stats (device,
- * iso_count records, may be NULL) is zeroed and filled on the stream.  d_taps members are device
+ * iso_count records, may be NULL) is zeroed and filled on the stream; a sweep call without it runs a kernel with
+ * the per-iso counting compiled out (15 ... 28 % faster: the reference's renderImage returns nodes_checked,
+ * src/raytrace.zig:21,105, so a caller that stands in for it passes d_stats).  d_taps members are device
  * pointers.  `stream` is a hipStream_t (NULL = the context's own stream).  Returns after
  * enqueueing.  A context's scratch serves one call at a time: calls on one context that may overlap in time
  * (different streams) are serialised by the caller or made on contexts of their own.  The scratch keeps the

@@ -57,6 +57,14 @@ def test_union_kernel_equals_per_iso_kernel_at_full_size(oracle, skull_vox, skul
     for k in (1, 2):
         assert (res[0][1] == res[k][1]).all(), np.argwhere(res[0][1] != res[k][1])[:8]
         assert bool(torch.equal(res[0][0], res[k][0]))
+    # a caller that passes no counters gets the kernel with everything that only serves them compiled out: the same frames,
+    # on a call the context remembers (tiles longest first, two cuts) and on one it does not (other rows)
+    for r0, r1 in ((0, H), (0, H), (37, 911)):
+        d_rgb = torch.full((256, r1 - r0, W, 3), 7, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        capi.check(L.vr_render_device(skull_renderer.handle, C.byref(v), 0, 256, r0, r1, d_rgb.data_ptr(), None, None, None), "vr_render_device")
+        capi.check(L.vr_sync(skull_renderer.handle), "vr_sync")
+        assert bool(torch.equal(d_rgb, res[0][0][:, r0:r1])), (r0, r1)
     # every frame's counters are the oracle's (tests/golden/fullsize_oracle.json, made by the CPU oracle)
     assert (res[0][1] == helpers.fullsize_golden_stats("skull_1024")).all() and int(res[0][1][:, 6].sum()) == 0
     si = capi.SweepInfo()
