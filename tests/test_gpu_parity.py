@@ -285,6 +285,32 @@ def test_calls_that_share_a_ray_list_match_the_oracle(oracle, skull_vox, skull_t
     call(pos, 512, 512, 75, 1, 0, 512)
 
 
+def test_frames_at_an_odd_address_are_cleared_whole(oracle, c60_vox, c60_tree, c60_renderer):
+    """The frames are set to zero by the library's own kernel, 16 bytes per store with the odd bytes at either end one by one:
+    a frame range that starts at an address that is not a multiple of 16 and has an odd length comes out as at an even one, and
+    the bytes in front of and behind it are left alone."""
+    import torch
+    pos, forw, up = oracle.main_camera(c60_vox.shape)
+    L = capi.lib()
+    W, H = 173, 91
+    v = vr.raytrace._view(pos, forw, up, W, H, 2.0)
+    for b, n in ((100, 1), (90, 3), (60, 20)):
+        size = n * H * W * 3
+        ref = torch.full((size,), 9, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        capi.check(L.vr_render_device(c60_renderer.handle, C.byref(v), b, n, 0, H, ref.data_ptr(), None, None, None), "vr_render_device")
+        capi.check(L.vr_sync(c60_renderer.handle), "vr_sync")
+        for off in (1, 5, 15):
+            buf = torch.full((size + 64,), 9, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            capi.check(L.vr_render_device(c60_renderer.handle, C.byref(v), b, n, 0, H, buf.data_ptr() + off, None, None, None), "vr_render_device")
+            capi.check(L.vr_sync(c60_renderer.handle), "vr_sync")
+            assert bool(torch.equal(buf[off:off + size], ref)), (b, n, off)
+            assert bool((buf[:off] == 9).all()) and bool((buf[off + size:] == 9).all()), (b, n, off)
+    ref0 = oracle.render(c60_tree[0], c60_tree[1], pos, forw, up, W, H, 2.0, 60)
+    assert (ref[:H * W * 3].cpu().numpy().reshape(H, W, 3) == ref0["rgb"]).all()
+
+
 def test_error_paths_on_device(c60_tree):
     nodes, rd, _ = c60_tree
     L = capi.lib()
