@@ -1801,8 +1801,9 @@ __global__ __launch_bounds__(64) void vr_k_union_fix(VrViewK v, const uint32_t *
                     if (go == VR_GO_MORE) continue;
                     if (go == VR_GO_HIT) { hit = true; break; }
                     moves++;
-                    if (A.checked > VR_MAX_CHECKED) { err = 1; break; }
-                    if (!vr_lane_move(A, v, esc)) break;
+                    const bool in_root_now = vr_lane_move(A, v, esc);
+                    if (A.checked > VR_MAX_CHECKED) { err = 1; break; } /* given up behind the MOVE, as in vr_k_trace */
+                    if (!in_root_now) break;
                     while (!vr_lane_pop(A, st, 64u)) {}
                 }
             }

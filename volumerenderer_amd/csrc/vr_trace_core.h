@@ -552,8 +552,11 @@ VR_HD VrHit vr_trace_resume(const VrViewK &v, const VrRay &ray, uint32_t iso, co
             break;
         }
         h.moves++;
+        const bool in_root = vr_lane_move(L, v, h.escapes);
+        /* the bound on a ray's checks (the reference's loop does not end on every ray): the MOVE is made and counted, then the
+         * ray is given up as a miss -- the same point at which the persistent kernels give it up, so that all counters agree */
         if (L.checked > VR_MAX_CHECKED) { h.error = 1; break; }
-        if (!vr_lane_move(L, v, h.escapes)) break;
+        if (!in_root) break;
         while (!vr_lane_pop(L, stack, max_trips)) {}
     }
     h.t = L.t;
