@@ -78,7 +78,7 @@ typedef struct vr_render_stats {
     uint64_t oob_count;
     uint64_t escape_help_events; /* :241 */
     uint64_t moves;              /* MOVE steps (:199-246); not counted by the reference            */
-    uint64_t errors;             /* rays abandoned: on a malformed tree (index or depth out of range), or after 2^27 checks.   */
+    uint64_t errors;             /* rays abandoned: on a malformed tree (index or depth out of range), or after 2^23 checks.   */
                                  /* The reference's loop does not end on every ray: a ray that runs along a lattice plane can   */
                                  /* alternate between two states for ever (MOVE takes the exit plane's t, which may lie behind  */
                                  /* the point, src/raytrace.zig:199-205) -- about 1 random far-away view in 100 has such a ray;  */

@@ -17,6 +17,9 @@ L = capi.lib()
 vols = {"skull": vr.Data.loadUCD(os.path.join(ROOT, "tests", "data", "Skull.vol.gz")),
         "c60": vr.Data.loadUCD(os.path.join(ROOT, "tests", "data", "C60.vol")),
         "standin256": vr.Data(datasets.bonsai_standin())}
+if os.environ.get("VR_STRESS_WIDE"):  # a volume beyond 256 voxels per axis: the wide node array and its kernels
+    vols = {"gyroid320": vr.Data(datasets.gyroid_noise(320))}
+print("volumes ready", flush=True)
 rnd = {}
 for name, data in vols.items():
     r = vr.Renderer(0); r.upload_volume(data); r.build_kdt("AlwaysCenter"); rnd[name] = r
@@ -31,10 +34,11 @@ def render(r, v, W, b, n, r0, r1, variant, with_stats):
     r.set_kernel(capi.KERNEL_DEFAULT)
     return d_rgb, d_stats.cpu().numpy()
 
+print("trees built", flush=True)
 t_end = time.time() + budget
 n_views = n_bad = n_err_views = 0
 while time.time() < t_end:
-    name = ["skull", "c60", "standin256"][int(rng.integers(3))]
+    name = list(vols)[int(rng.integers(len(vols)))]
     data, r = vols[name], rnd[name]
     res = np.array(data.resulution, dtype=np.float64)
     centre = res / 2.0
@@ -47,8 +51,9 @@ while time.time() < t_end:
     r0 = int(rng.integers(0, H // 3)); r1 = int(rng.integers(r0 + 1, H + 1)) if rng.random() < 0.5 else H
     vp = float(rng.uniform(0.8, 3.0))
     v = vr.raytrace._view(tuple(pos), tuple(forw), tuple(up), W, H, vp)
-    ref = render(r, v, W, b, n, r0, r1, capi.KERNEL_PIPELINE, True)
     what = "%s %dx%d rows %d..%d iso %d+%d" % (name, W, H, r0, r1, b, n)
+    if os.environ.get("VR_STRESS_VERBOSE"): print("view %d: %s at %.1f s" % (n_views, what, time.time() - t_end + budget), flush=True)
+    ref = render(r, v, W, b, n, r0, r1, capi.KERNEL_PIPELINE, True)
     for i in range(3):
         got = render(r, v, W, b, n, r0, r1, capi.KERNEL_DEFAULT, True)
         if not (got[1] == ref[1]).all() or not bool(torch.equal(got[0], ref[0])):

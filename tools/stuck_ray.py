@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: one of the views in which tools/stress_union.py counted `errors` (a ray past the bound of 2^27 checks): which pixel
+"""GPU box: one of the views in which tools/stress_union.py counted `errors` (a ray past the bound on its checks): which pixel
 is it, and what do the first and the last recorded steps of its literal walk (vr_trace_ray, the reference's loop) look like?"""
 import ctypes as C, os, sys
 import numpy as np

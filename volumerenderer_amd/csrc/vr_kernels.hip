@@ -1858,8 +1858,9 @@ __global__ __launch_bounds__(64) void vr_k_union_fix_wide(VrViewK v, const uint3
                     const uint32_t go = vr_wide_descend(A, v, iso, fetch, path, VR_WIDE_MAX_DEPTH + 1u);
                     if (go == VR_GO_HIT) { hit = true; break; }
                     moves++;
-                    if (A.checked > VR_MAX_CHECKED) { err = 1; break; }
-                    if (!vr_wide_move(A, v, esc)) break;
+                    const bool in_root_now = vr_wide_move(A, v, esc);
+                    if (A.checked > VR_MAX_CHECKED) { err = 1; break; } /* given up behind the MOVE, as in every kernel */
+                    if (!in_root_now) break;
                     while (!vr_wide_pop(A, path, 64u)) {}
                 }
             }
@@ -2035,14 +2036,10 @@ __global__ __launch_bounds__(kWideThreads) void vr_k_trace_wide(
                         if (taps.node) taps.node[tap_base + pix] = L.idx;
                     }
                 } else if (go == VR_GO_EXCLUDED) {
-                    bool on = false;
-                    if (L.checked <= VR_MAX_CHECKED) {
-                        a_moves++;
-                        on = vr_wide_move(L, v, a_esc);
-                        popping = on;
-                    } else { /* safety valve, never reached on a valid tree */
-                        a_err++;
-                    }
+                    a_moves++;
+                    bool on = vr_wide_move(L, v, a_esc);
+                    if (L.checked > VR_MAX_CHECKED) { on = false; a_err++; } /* the bound on a ray's checks: given up behind the MOVE, as in vr_k_trace */
+                    popping = on;
                     if (!on) { /* left the volume: a miss, the pixel stays black (src/raytrace.zig:66-68) */
                         a_miss++;
                         alive = false;

@@ -288,7 +288,12 @@ VR_HD VrHit vr_trace_restart(const VrViewK &v, const VrRay &ray, uint32_t iso, N
  * without moving, depth() is the current level.
  * ---------------------------------------------------------------------------------------- */
 #define VR_N_LEAF 0x80000000u
-#define VR_MAX_CHECKED (1u << 27) /* safety valve per ray; a 256^3 volume stays far below it */
+/* The bound on a ray's checks.  The reference's loop does not end on every ray (one that runs along a lattice plane can alternate
+ * between two states for ever: about 1 random far-away view in 100 has such a ray, the reference's own views have none); here such a
+ * ray is given up as a miss and counted in vr_render_stats.errors.  The longest walks of valid rays are a few thousand checks (Skull
+ * 1024^2: 1 847; a ray through all of a 1024^3 volume: below 10^5), so 2^23 leaves a factor of a hundred and costs a launch with a
+ * stuck ray about a second (2^27: 17 s on a 256^3 volume, minutes on the wide node array). */
+#define VR_MAX_CHECKED (1u << 23)
 
 /* n / d, correctly rounded, from r = RN(1 / d): two FMA residual corrections of n * r.  With r the
  * correctly rounded reciprocal, the first correction makes the quotient faithful and the second one

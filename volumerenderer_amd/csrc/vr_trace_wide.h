@@ -240,9 +240,10 @@ VR_HD VrHit vr_trace_wide_impl(const VrViewK &v, const VrRay &ray, uint32_t iso,
             go = vr_wide_descend(L, v, iso, fetch, path, VR_WIDE_MAX_DEPTH + 1u);
         }
         if (go == VR_GO_HIT) { h.flag = 1u; h.node = L.idx; h.cell = L.c; break; }
-        if (L.checked > VR_MAX_CHECKED) { h.error = 1; break; } /* safety valve, never reached on a valid tree */
         h.moves++;
-        if (!vr_wide_move(L, v, h.escapes)) break;
+        const bool in_root = vr_wide_move(L, v, h.escapes);
+        if (L.checked > VR_MAX_CHECKED) { h.error = 1; break; } /* the bound on a ray's checks: given up behind the MOVE, as in the persistent kernels */
+        if (!in_root) break;
         while (!vr_wide_pop(L, path, pop_trips)) {}
     }
     h.t = L.t;
