@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU box: random views of Skull, C60 and the 256^3 stand-in -- camera anywhere around the volume, image sizes up to 900 x 700,
+"""GPU box (VR_STRESS_WIDE=1: a 320^3 volume on the wide node array; VR_STRESS_NOALLOC=1: the default selection through
+vr_render_device_noalloc): random views of Skull, C60 and the 256^3 stand-in -- camera anywhere around the volume, image sizes up to 900 x 700,
 iso ranges of 8 .. 256 values, row ranges -- rendered by the default kernel selection (the union kernel: first call, repeated calls with
 the tiles longest first and two cuts, with and without counters) and by the kernel with one traversal per iso value; frames and all
 counters must be identical.  usage: python tools/stress_union.py [seconds] [seed]"""
@@ -29,7 +30,8 @@ def render(r, v, W, b, n, r0, r1, variant, with_stats):
     d_rgb = torch.full((n, r1 - r0, W, 3), 5, dtype=torch.uint8, device="cuda")
     d_stats = torch.zeros((n, 7), dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
-    capi.check(L.vr_render_device(r.handle, C.byref(v), b, n, r0, r1, d_rgb.data_ptr(), d_stats.data_ptr() if with_stats else None, None, None), "render")
+    fn = L.vr_render_device_noalloc if (variant == capi.KERNEL_DEFAULT and os.environ.get("VR_STRESS_NOALLOC")) else L.vr_render_device
+    capi.check(fn(r.handle, C.byref(v), b, n, r0, r1, d_rgb.data_ptr(), d_stats.data_ptr() if with_stats else None, None, None), "render")
     capi.check(L.vr_sync(r.handle), "sync")
     r.set_kernel(capi.KERNEL_DEFAULT)
     return d_rgb, d_stats.cpu().numpy()
