@@ -386,7 +386,7 @@ typedef struct vr_sweep_info {
                                    * started its tiles of 64 rays in the order of the item lengths that call left (longest first);
                                    * 0 = a call it has not seen: the tiles in the order of their rays' chords, or list order */
     uint32_t rendered_again; /* union kernel: 1 when it could not finish the call exactly (more than 32 768 runs of iso values left
-                              * its walks, or one front passed 2^20 MOVEs) and the call was rendered again, on the same stream and
+                              * its walks, or one front passed 2^17 MOVEs) and the call was rendered again, on the same stream and
                               * before anything the caller enqueued behind it, by the kernel that shares traversals between iso
                               * values; frames and counters are the same either way */
     uint32_t reserved;

@@ -116,14 +116,16 @@ def test_gpu_refinement_pass_equals_the_oracle(oracle, c60_vox, skull_vox):
             tt = np.stack([o["t"][0] for o in out])
             d_cf, d_t = torch.from_numpy(cf).cuda(), torch.from_numpy(tt).cuda()
             d_den = torch.full((n, H, W), -1.0, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()  # the fills run on torch's stream, the library's kernels on the context's own
             capi.check(L.vr_refine_device(r.handle, C.byref(v), n, 0, H, d_cf.data_ptr(), d_t.data_ptr(), d_den.data_ptr(), None),
                        "vr_refine_device")
             capi.check(L.vr_sync(r.handle), "vr_sync")
             den = d_den.cpu().numpy()
             # a row range of one frame
             d_part = torch.full((1, 40, W), -1.0, dtype=torch.float32, device="cuda")
-            capi.check(L.vr_refine_device(r.handle, C.byref(v), 1, 50, 90, d_cf[0, 50:90].contiguous().data_ptr(),
-                                          d_t[0, 50:90].contiguous().data_ptr(), d_part.data_ptr(), None), "vr_refine_device")
+            a_cf, a_t = d_cf[0, 50:90].contiguous(), d_t[0, 50:90].contiguous()
+            torch.cuda.synchronize()
+            capi.check(L.vr_refine_device(r.handle, C.byref(v), 1, 50, 90, a_cf.data_ptr(), a_t.data_ptr(), d_part.data_ptr(), None), "vr_refine_device")
             capi.check(L.vr_sync(r.handle), "vr_sync")
             assert (d_part.cpu().numpy()[0].view(np.uint32) == den[0, 50:90].view(np.uint32)).all()
         for k, iso in enumerate(isos):

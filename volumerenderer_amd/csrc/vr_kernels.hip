@@ -1257,7 +1257,10 @@ constexpr uint32_t kUnionDescendTrips = VR_UNION_DESCEND_TRIPS, kUnionPopTrips =
 constexpr uint32_t kUnionRefillMin = VR_UNION_REFILL_MIN;
 constexpr uint32_t kParkMoveShift = 35u; /* see UnionSink::park */
 constexpr uint32_t kUnionFineShift = VR_UNION_FINE_SHIFT, kUnionFineMul = VR_UNION_FINE_MUL;
-constexpr uint32_t kUnionMaxStates = 1u << 20; /* MOVEs of one front: the safety valve (VR_MAX_CHECKED in the other kernels) */
+/* MOVEs of one front: the safety valve (VR_MAX_CHECKED in the other kernels).  A valid front makes one MOVE per cell its ray crosses
+ * at most -- a few thousand on the largest volume; a front with a ray on which the reference's loop does not end would go on for
+ * ever: it is given up here (half a second) and the call rendered again by the kernel that bounds every ray by its checks. */
+constexpr uint32_t kUnionMaxStates = 1u << 17;
 
 struct VrUnionRecord { uint32_t ray, run, t_bits, cell, esc, pad[3]; }; /* run = r0 | r1 << 8 | in_root << 16 */
 
