@@ -23,6 +23,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_fills_before_library_kernels():
+    """The library's streams are non-blocking: they do not wait for torch's default stream.  A test that fills a tensor
+    with torch (torch.zeros, torch.full, a slice copy) and hands its pointer to the library in the next statement races
+    with that fill.  Ordered here once, for every entry point that takes device pointers: torch's work is waited for
+    before the library's call is made."""
+    if torch is None or not torch.cuda.is_available():
+        yield
+        return
+    from volumerenderer_amd import capi
+    L = capi.lib()
+    for name in ("vr_render_device", "vr_render_device_noalloc", "vr_render_device_bands", "vr_refine_device", "vr_trilerp_device"):
+        fn = getattr(L, name)
+
+        def ordered(*args, _fn=fn):
+            torch.cuda.synchronize()
+            return _fn(*args)
+        setattr(L, name, ordered)
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
